@@ -1,0 +1,229 @@
+"""ctypes binding of the C ABI (include/faldoi_hip.h) -- the binding a host-language caller
+would write; used by tests/, bench.py and __graft_entry__.  No torch types cross this boundary.
+
+Fails loudly when libfaldoi_hip.so is missing: there is no CPU fallback in the product.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_F = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = range(6)
+MAX_CHUNK = 16
+
+# every symbol include/faldoi_hip.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "faldoi_abi_version", "faldoi_device_count", "faldoi_ctx_create", "faldoi_ctx_destroy",
+    "faldoi_ctx_synchronize", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
+    "faldoi_tvl1_batch_create", "faldoi_tvl1_batch_destroy", "faldoi_tvl1_batch_upload",
+    "faldoi_tvl1_batch_reset", "faldoi_tvl1_batch_solve", "faldoi_tvl1_batch_download",
+    "faldoi_tvl1_batch_last_timing", "faldoi_centered_gradient", "faldoi_forward_gradient",
+    "faldoi_divergence", "faldoi_bicubic_warp",
+]
+
+
+class Tvl1Params(C.Structure):
+    _fields_ = [("lambda_", C.c_float), ("theta", C.c_float), ("tau", C.c_float), ("tol", C.c_float),
+                ("warps", C.c_int), ("max_inner", C.c_int), ("tol_stop", C.c_int), ("chunk", C.c_int),
+                ("verbose", C.c_int)]
+
+
+class Tvl1Stats(C.Structure):
+    _fields_ = [("total_iters", C.c_long), ("warps", C.c_int), ("iters_cap", C.c_int),
+                ("iters", C.POINTER(C.c_int)), ("err", C.POINTER(C.c_float)),
+                ("solve_ms", C.c_double), ("chunk_launches", C.c_int)]
+
+
+class FaldoiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("faldoi_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def library_path():
+    return _build.SO
+
+
+def lib():
+    """Loads libfaldoi_hip.so (building it if the sources are newer).  Raises if it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = _build.SO
+    if _build.needs_build():
+        so = _build.build()
+    if not os.path.exists(so):
+        raise RuntimeError("libfaldoi_hip.so is missing and could not be built; the HIP path has no fallback")
+    L = C.CDLL(so)
+    vp = C.c_void_p
+    L.faldoi_abi_version.restype = C.c_int
+    L.faldoi_last_error.restype = C.c_char_p
+    L.faldoi_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.faldoi_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.faldoi_ctx_destroy.argtypes = [vp]
+    L.faldoi_ctx_destroy.restype = None
+    L.faldoi_ctx_synchronize.argtypes = [vp]
+    L.faldoi_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
+    L.faldoi_tvl1_default_params.restype = None
+    L.faldoi_tvl1_global.argtypes = [vp, _F, _F, _F, vp, C.c_int, C.c_int, C.POINTER(Tvl1Params),
+                                     C.POINTER(Tvl1Stats)]
+    L.faldoi_tvl1_batch_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.faldoi_tvl1_batch_destroy.argtypes = [vp]
+    L.faldoi_tvl1_batch_destroy.restype = None
+    L.faldoi_tvl1_batch_upload.argtypes = [vp, C.c_int, _F, _F, _F, vp]
+    L.faldoi_tvl1_batch_reset.argtypes = [vp]
+    L.faldoi_tvl1_batch_solve.argtypes = [vp, C.POINTER(Tvl1Params), C.POINTER(Tvl1Stats)]
+    L.faldoi_tvl1_batch_download.argtypes = [vp, C.c_int, _F, vp]
+    L.faldoi_tvl1_batch_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                                C.POINTER(C.c_long)]
+    L.faldoi_centered_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
+    L.faldoi_forward_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
+    L.faldoi_divergence.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
+    L.faldoi_bicubic_warp.argtypes = [vp, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise FaldoiError(rc, lib().faldoi_last_error().decode("utf-8", "replace"))
+
+
+def default_params(**over):
+    p = Tvl1Params()
+    lib().faldoi_tvl1_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, "lambda_" if k in ("lambda", "lam") else k, v)
+    return p
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One device + one HIP stream (faldoi_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().faldoi_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib().faldoi_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- primitives (host arrays in/out) ----
+    def centered_gradient(self, img):
+        img = _f32(img)
+        h, w = img.shape
+        dx, dy = np.empty_like(img), np.empty_like(img)
+        _check(lib().faldoi_centered_gradient(self._h, img, dx, dy, w, h))
+        return dx, dy
+
+    def forward_gradient(self, img):
+        img = _f32(img)
+        h, w = img.shape
+        fx, fy = np.empty_like(img), np.empty_like(img)
+        _check(lib().faldoi_forward_gradient(self._h, img, fx, fy, w, h))
+        return fx, fy
+
+    def divergence(self, v1, v2):
+        v1, v2 = _f32(v1), _f32(v2)
+        h, w = v1.shape
+        d = np.empty_like(v1)
+        _check(lib().faldoi_divergence(self._h, v1, v2, d, w, h))
+        return d
+
+    def bicubic_warp(self, img, u, v, border_out=True):
+        img, u, v = _f32(img), _f32(u), _f32(v)
+        h, w = img.shape
+        o = np.empty_like(img)
+        _check(lib().faldoi_bicubic_warp(self._h, img, u, v, o, w, h, int(bool(border_out))))
+        return o
+
+    # ---- one-call solver (mirror of tvl2OF) ----
+    def tvl1_global(self, i0n, i1n, u0, xi=None, **params):
+        i0n, i1n = _f32(i0n), _f32(i1n)
+        h, w = i0n.shape
+        u = _f32(u0).copy()
+        xi = None if xi is None else _f32(xi).copy()
+        p = default_params(**params)
+        iters = np.zeros(p.warps, np.int32)
+        errs = np.zeros(p.warps, np.float32)
+        st = Tvl1Stats(iters_cap=p.warps, iters=iters.ctypes.data_as(C.POINTER(C.c_int)),
+                       err=errs.ctypes.data_as(C.POINTER(C.c_float)))
+        _check(lib().faldoi_tvl1_global(self._h, i0n, i1n, u, _ptr(xi), w, h, C.byref(p), C.byref(st)))
+        return u, iters, errs, xi, st.solve_ms
+
+
+class Tvl1Batch:
+    """npairs same-size pairs resident in HBM (faldoi_tvl1_batch)."""
+
+    def __init__(self, ctx, npairs, w, h):
+        self.ctx, self.npairs, self.w, self.h = ctx, int(npairs), int(w), int(h)
+        self._h = C.c_void_p()
+        _check(lib().faldoi_tvl1_batch_create(ctx._h, self.npairs, self.w, self.h, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().faldoi_tvl1_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, pair, i0n, i1n, u0, xi=None):
+        xi = None if xi is None else _f32(xi)
+        _check(lib().faldoi_tvl1_batch_upload(self._h, int(pair), _f32(i0n), _f32(i1n), _f32(u0), _ptr(xi)))
+
+    def solve(self, **params):
+        p = default_params(**params)
+        n = self.npairs
+        iters = np.zeros((n, p.warps), np.int32)
+        errs = np.zeros((n, p.warps), np.float32)
+        stats = (Tvl1Stats * n)()
+        for i in range(n):
+            stats[i].iters_cap = p.warps
+            stats[i].iters = iters[i].ctypes.data_as(C.POINTER(C.c_int))
+            stats[i].err = errs[i].ctypes.data_as(C.POINTER(C.c_float))
+        _check(lib().faldoi_tvl1_batch_solve(self._h, C.byref(p), stats))
+        return iters, errs, stats[0].solve_ms, stats[0].chunk_launches
+
+    def last_timing(self):
+        ms, nl, pi = C.c_double(), C.c_int(), C.c_long()
+        _check(lib().faldoi_tvl1_batch_last_timing(self._h, C.byref(ms), C.byref(nl), C.byref(pi)))
+        return ms.value, nl.value, pi.value
+
+    def download(self, pair, want_xi=False):
+        u = np.empty((2, self.h, self.w), np.float32)
+        xi = np.empty((4, self.h, self.w), np.float32) if want_xi else None
+        _check(lib().faldoi_tvl1_batch_download(self._h, int(pair), u, _ptr(xi)))
+        return (u, xi) if want_xi else u

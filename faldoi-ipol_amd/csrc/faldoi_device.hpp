@@ -1,0 +1,209 @@
+// faldoi_device.hpp -- per-pixel device functions of the FALDOI TV-L1 path (gfx950).
+//
+// Everything here is a pure function of values held in registers; the kernels in
+// tvl1_kernels.hpp decide where those values come from (HBM, LDS, a neighbouring lane).
+// Parity contract: each function evaluates the reference's floating-point expression tree
+// (file:line cited, upstream repo fperezgamonal/faldoi-ipol) with the same association and
+// the same precision per operation.  The translation unit is compiled with
+// -ffp-contract=off (no fused multiply-add), hipcc's default correctly-rounded fp32
+// divide/sqrt and IEEE denormals, so results are bit-identical to the CPU path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#pragma clang fp contract(off)
+
+namespace faldoi {
+
+// Smallest float that is NOT below the reference's double threshold GRAD_IS_ZERO = 1E-8
+// (src/parameters.h:45): for float g, ((double)g < 1E-8) == (g < kGradZeroF).
+// (float)1e-8 = 0x322bcc77 = 9.99999994e-09 < 1e-8, so the bound is the next float up.
+__device__ __forceinline__ float grad_zero_bound() { return __uint_as_float(0x322bcc78u); }
+
+// ---------------------------------------------------------------------------------------------
+// Stencil classes of a pixel (its position relative to the image frame).
+// ---------------------------------------------------------------------------------------------
+struct PixClass {
+    bool first_c, last_c, first_r, last_r;
+};
+__device__ __forceinline__ PixClass classify(int x, int y, int nx, int ny)
+{
+    return PixClass{ x == 0, x == nx - 1, y == 0, y == ny - 1 };
+}
+
+// src/utils.cpp:367-423 centered_gradient: 0.5*(next - prev); on the frame the missing side is
+// replaced by the pixel itself (one-sided, still halved).  The subtraction is fp32, the product
+// with the double literal 0.5 is fp64, stored as fp32 (exact: halving never rounds except for
+// denormals, where the fp64 product is still exact and rounds once).
+__device__ __forceinline__ float centered_diff(float next, float prev)
+{
+    const float d = next - prev;
+    return (float)(0.5 * (double)d);
+}
+
+// src/utils.cpp:285-323 forward_gradient: zero on the last column / last row.
+__device__ __forceinline__ float fwd_diff(float next, float self, bool is_last)
+{
+    return is_last ? 0.0f : next - self;
+}
+
+// src/utils.cpp:239-283 divergence, all nine border classes.
+// a = v1[p], al = v1[p-1], b = v2[p], bu = v2[p-nx]; values whose class does not use them
+// may be anything (they are never touched by the selected expression's result).
+__device__ __forceinline__ float div_sample(float a, float al, float b, float bu, const PixClass c)
+{
+    const bool inner_c = !c.first_c && !c.last_c;
+    // horizontal part: interior v1[p]-v1[p-1]; first column v1[p]; last column -v1[p-1]
+    const float h = inner_c ? (a - al) : (c.first_c ? a : -al);
+    // rows: first row adds v2[p] (:263,:278,:279); last row subtracts v2[p-nx] (:264,:280,:281)
+    const float r_first = h + b;
+    const float r_last = h - bu;
+    // middle rows: interior columns v1x + (v2[p]-v2[p-nx]) (:250-256); frame columns are written
+    // left-to-right in the reference, (h + v2[p]) - v2[p-nx] (:272-273)
+    const float r_mid = inner_c ? h + (b - bu) : (h + b) - bu;
+    return c.first_r ? r_first : (c.last_r ? r_last : r_mid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bicubic interpolation, src/bicubic_interpolation.c:26-40,103-237.
+// ---------------------------------------------------------------------------------------------
+struct BicubicTaps {
+    int X[4];      // tap columns in the reference's order: minus, centre, plus, plus-plus
+    int Y[4];      // tap rows, same order
+    float tx, ty;  // fractional offsets (uu - x, vv - y) against the CLAMPED centre
+    bool clamped;  // any index was clamped ("out" in the reference)
+};
+
+__device__ __forceinline__ int clamp_flag(int i, int n, bool &clamped)
+{
+    if (i < 0) { clamped = true; return 0; }
+    if (i >= n) { clamped = true; return n - 1; }
+    return i;
+}
+
+// :138-166.  (int) truncates toward zero; the "minus" row uses sx, not sy (reference quirk, :159).
+__device__ __forceinline__ BicubicTaps bicubic_taps(float uu, float vv, int nx, int ny)
+{
+    BicubicTaps t;
+    const int sx = (uu < 0) ? -1 : 1;
+    const int sy = (vv < 0) ? -1 : 1;
+    const int iu = (int)uu, iv = (int)vv;
+    t.clamped = false;
+    const int x = clamp_flag(iu, nx, t.clamped);
+    const int y = clamp_flag(iv, ny, t.clamped);
+    t.X[0] = clamp_flag(iu - sx, nx, t.clamped);
+    t.Y[0] = clamp_flag(iv - sx, ny, t.clamped);
+    t.X[1] = x;
+    t.Y[1] = y;
+    t.X[2] = clamp_flag(iu + sx, nx, t.clamped);
+    t.Y[2] = clamp_flag(iv + sy, ny, t.clamped);
+    t.X[3] = clamp_flag(iu + 2 * sx, nx, t.clamped);
+    t.Y[3] = clamp_flag(iv + 2 * sy, ny, t.clamped);
+    t.tx = uu - (float)x;
+    t.ty = vv - (float)y;
+    return t;
+}
+
+// :103-111 cubic_interpolation_cell.  (v2-v0) and (v1-v2) are fp32 subtractions; everything
+// that touches a double literal is fp64; one rounding to fp32 at the end.
+__device__ __forceinline__ float keys_cubic(float v0, float v1, float v2, float v3, float t)
+{
+    const float d20 = v2 - v0;
+    const float d12 = v1 - v2;
+    const double td = (double)t;
+    const double c3 = 3.0 * (double)d12 + (double)v3 - (double)v0;
+    const double c2 = 2.0 * (double)v0 - 5.0 * (double)v1 + 4.0 * (double)v2 - (double)v3 + td * c3;
+    const double c1 = (double)d20 + td * c2;
+    return (float)((double)v1 + 0.5 * td * c1);
+}
+
+// :113-131,:199-236: 16 gathers, four column cubics along y, one cubic along x.
+__device__ __forceinline__ float bicubic_eval(const float *__restrict__ img, const BicubicTaps &t, int nx)
+{
+    float col[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float p0 = img[t.X[a] + nx * t.Y[0]];
+        const float p1 = img[t.X[a] + nx * t.Y[1]];
+        const float p2 = img[t.X[a] + nx * t.Y[2]];
+        const float p3 = img[t.X[a] + nx * t.Y[3]];
+        col[a] = keys_cubic(p0, p1, p2, p3, t.ty);
+    }
+    return keys_cubic(col[0], col[1], col[2], col[3], t.tx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TV-L1 per-pixel steps, src/global_faldoi.cpp.
+// ---------------------------------------------------------------------------------------------
+
+// :647-657 per-warp constants.
+__device__ __forceinline__ float rho_const(float I1w, float I1wx, float I1wy, float u1, float u2, float I0)
+{
+    return I1w - I1wx * u1 - I1wy * u2 - I0;
+}
+__device__ __forceinline__ float grad_sq(float I1wx, float I1wy)
+{
+    const float Ix2 = I1wx * I1wx;
+    const float Iy2 = I1wy * I1wy;
+    return Ix2 + Iy2;
+}
+
+// :690-718 thresholding step: v = u + TH(rho, grad).
+__device__ __forceinline__ void threshold_step(float rho_c, float I1wx, float I1wy, float grad,
+                                               float u1, float u2, float l_t, float &v1, float &v2)
+{
+    const float rho = rho_c + (I1wx * u1 + I1wy * u2);
+    const float lg = l_t * grad;
+    float d1, d2;
+    if (rho < -lg) {                 // (-l_t)*grad == -(l_t*grad) exactly
+        d1 = l_t * I1wx;
+        d2 = l_t * I1wy;
+    } else if (rho > lg) {
+        d1 = -l_t * I1wx;
+        d2 = -l_t * I1wy;
+    } else if (grad < grad_zero_bound()) {
+        d1 = 0.0f;
+        d2 = 0.0f;
+    } else {
+        const float fi = -rho / grad;
+        d1 = fi * I1wx;
+        d2 = fi * I1wy;
+    }
+    v1 = u1 + d1;
+    v2 = u2 + d2;
+}
+
+// :349-381 ofTVl2_getD: xi <- (xi + tau * grad(ubar)) / max(1, |xi_old|).  Step tau (not
+// tau/theta) and the norm of the PRE-update duals: reference behaviour, reproduced.
+__device__ __forceinline__ void dual_step(float &xi11, float &xi12, float &xi21, float &xi22,
+                                          float u1x, float u1y, float u2x, float u2y, float tau)
+{
+    const float g11 = xi11 * xi11;
+    const float g12 = xi12 * xi12;
+    const float g21 = xi21 * xi21;
+    const float g22 = xi22 * xi22;
+    float n = sqrtf(g11 + g12 + g21 + g22);
+    n = (1.0f > n) ? 1.0f : n;
+    xi11 = (xi11 + tau * u1x) / n;
+    xi12 = (xi12 + tau * u1y) / n;
+    xi21 = (xi21 + tau * u2x) / n;
+    xi22 = (xi22 + tau * u2y) / n;
+}
+
+// :307-342 ofTVl2_getP for one pixel, followed by the over-relaxation of :780-783.
+// Returns |du|^2 (u_N).
+__device__ __forceinline__ float primal_step(float &u1, float &u2, float &ub1, float &ub2,
+                                             float v1, float v2, float div1, float div2,
+                                             float theta, float tau)
+{
+    const float u1k = u1, u2k = u2;
+    const float n1 = u1k - tau * (-div1 + (u1k - v1) / theta);
+    const float n2 = u2k - tau * (-div2 + (u2k - v2) / theta);
+    const float e = (n1 - u1k) * (n1 - u1k) + (n2 - u2k) * (n2 - u2k);
+    u1 = n1;
+    u2 = n2;
+    ub1 = 2.0f * n1 - u1k;
+    ub2 = 2.0f * n2 - u2k;
+    return e;
+}
+
+}  // namespace faldoi

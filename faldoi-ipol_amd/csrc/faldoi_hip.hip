@@ -1,0 +1,567 @@
+// faldoi_hip.hip -- host side of libfaldoi_hip.so (C ABI declared in include/faldoi_hip.h).
+//
+// Owns: device selection, one HIP stream per context, the HBM slabs of a batch, and the launch
+// schedule of the fused TV-L1 kernel.  There is no CPU compute path in this library: every
+// entry point either launches HIP kernels or fails with a status code.
+#include "faldoi_hip.h"
+#include "tvl1_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace faldoi;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? FALDOI_ERR_OOM : FALDOI_ERR_HIP,           \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ types
+struct faldoi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int *h_done = nullptr;            // pinned
+    int n_cu = 256;
+};
+
+struct faldoi_tvl1_batch {
+    faldoi_ctx *ctx = nullptr;
+    int npairs = 0, nx = 0, ny = 0;
+    size_t plane_elems = 0;
+    float *slabs = nullptr;           // [npairs][P_COUNT][plane_elems]
+    PairCtl *ctl = nullptr;           // [npairs]
+    float *err_part = nullptr;        // [slots][npairs*ntiles][kMaxChunk]
+    size_t err_part_elems = 0;
+    int *d_iters = nullptr;           // [npairs][warps]
+    float *d_err = nullptr;
+    int stats_cap = 0;
+    int *d_done = nullptr;
+    std::vector<int> final_cur;       // which state buffer holds each pair's result
+    std::vector<char> uploaded;
+    bool solved = false;
+    double last_ms = 0.0;
+    int last_launches = 0;
+    long last_px_iters = 0;
+};
+
+static int check_device(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        if (count) *count = 0;
+        return fail(FALDOI_ERR_NO_DEVICE, "no HIP device available (%s)",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    if (count) *count = n;
+    return FALDOI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ context
+extern "C" int faldoi_abi_version(void) { return FALDOI_ABI_VERSION; }
+
+extern "C" const char *faldoi_last_error(void) { return g_err; }
+
+extern "C" int faldoi_device_count(int *count)
+{
+    if (!count) return fail(FALDOI_ERR_INVALID, "count is NULL");
+    return check_device(count);
+}
+
+extern "C" void faldoi_tvl1_default_params(faldoi_tvl1_params *p)
+{
+    if (!p) return;
+    p->lambda = FALDOI_DEFAULT_LAMBDA;
+    p->theta = FALDOI_DEFAULT_THETA;
+    p->tau = FALDOI_DEFAULT_TAU;
+    p->tol = FALDOI_DEFAULT_TOL;
+    p->warps = FALDOI_DEFAULT_WARPS_GLOBAL;
+    p->max_inner = FALDOI_DEFAULT_MAX_INNER;
+    p->tol_stop = 1;
+    p->chunk = 0;
+    p->verbose = 0;
+}
+
+extern "C" int faldoi_ctx_create(int device, faldoi_ctx **out)
+{
+    if (!out) return fail(FALDOI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    int rc = check_device(&n);
+    if (rc) return rc;
+    if (device < 0 || device >= n) return fail(FALDOI_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    faldoi_ctx *c = new (std::nothrow) faldoi_ctx;
+    if (!c) return fail(FALDOI_ERR_OOM, "host allocation failed");
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_done, sizeof(int), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        faldoi_ctx_destroy(c);
+        return fail(FALDOI_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return FALDOI_OK;
+}
+
+extern "C" void faldoi_ctx_destroy(faldoi_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->h_done) (void)hipHostFree(c->h_done);
+    delete c;
+}
+
+extern "C" int faldoi_ctx_synchronize(faldoi_ctx *c)
+{
+    if (!c) return fail(FALDOI_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FALDOI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ tiling
+struct TileCfg {
+    int R, NW;           // rows per thread, waves per workgroup (tile = 64 x R*NW)
+};
+
+static TileCfg pick_tile()
+{
+    TileCfg t{4, 16};
+    if (const char *s = getenv("FALDOI_TILE")) {     // tuning aid: "R,NW"
+        int r = 0, w = 0;
+        if (sscanf(s, "%d,%d", &r, &w) == 2) {
+            if ((r == 4 && w == 16) || (r == 8 && w == 8) || (r == 4 && w == 8) || (r == 2 && w == 16) ||
+                (r == 6 && w == 8) || (r == 3 && w == 16))
+                t = TileCfg{r, w};
+        }
+    }
+    return t;
+}
+
+template <int R, int NW>
+static hipError_t launch_chunk_t(dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int ntx, int nty,
+                                 int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st, int cur,
+                                 int first, int iters, int slot)
+{
+    hipLaunchKernelGGL((tvl1_chunk_kernel<R, NW>), grid, dim3(64 * NW), 0, s, base, pe, nx, ny, ntx, nty, npairs, halo,
+                       prm, ctl, err, st, cur, first, iters, slot);
+    return hipGetLastError();
+}
+
+static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int ntx,
+                               int nty, int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st,
+                               int cur, int first, int iters, int slot)
+{
+#define FALDOI_CASE(r, w)                                                                                             \
+    if (tc.R == r && tc.NW == w)                                                                                      \
+        return launch_chunk_t<r, w>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, first, \
+                                    iters, slot);
+    FALDOI_CASE(4, 16)
+    FALDOI_CASE(8, 8)
+    FALDOI_CASE(4, 8)
+    FALDOI_CASE(2, 16)
+    FALDOI_CASE(6, 8)
+    FALDOI_CASE(3, 16)
+#undef FALDOI_CASE
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------ batch
+extern "C" int faldoi_tvl1_batch_create(faldoi_ctx *ctx, int npairs, int nx, int ny, faldoi_tvl1_batch **out)
+{
+    if (!ctx || !out) return fail(FALDOI_ERR_INVALID, "ctx/out is NULL");
+    *out = nullptr;
+    if (npairs < 1 || npairs > 256) return fail(FALDOI_ERR_INVALID, "npairs=%d outside 1..256", npairs);
+    if (nx < 2 || ny < 2 || (long)nx * ny > (1L << 28))
+        return fail(FALDOI_ERR_INVALID, "image size %dx%d unsupported (need >= 2x2, <= 2^28 px)", nx, ny);
+    HIP_TRY(hipSetDevice(ctx->device));
+    faldoi_tvl1_batch *b = new (std::nothrow) faldoi_tvl1_batch;
+    if (!b) return fail(FALDOI_ERR_OOM, "host allocation failed");
+    b->ctx = ctx;
+    b->npairs = npairs;
+    b->nx = nx;
+    b->ny = ny;
+    b->plane_elems = (((size_t)nx * ny + 63) / 64) * 64;
+    b->final_cur.assign(npairs, 0);
+    b->uploaded.assign(npairs, 0);
+    const size_t bytes = (size_t)npairs * P_COUNT * b->plane_elems * sizeof(float);
+    hipError_t e = hipMalloc((void **)&b->slabs, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(b->slabs, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->ctl, sizeof(PairCtl) * npairs);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_done, sizeof(int));
+    if (e != hipSuccess) {
+        faldoi_tvl1_batch_destroy(b);
+        return fail(e == hipErrorOutOfMemory ? FALDOI_ERR_OOM : FALDOI_ERR_HIP, "batch allocation of %zu bytes failed: %s",
+                    bytes, hipGetErrorString(e));
+    }
+    *out = b;
+    return FALDOI_OK;
+}
+
+extern "C" void faldoi_tvl1_batch_destroy(faldoi_tvl1_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->slabs) (void)hipFree(b->slabs);
+    if (b->ctl) (void)hipFree(b->ctl);
+    if (b->err_part) (void)hipFree(b->err_part);
+    if (b->d_iters) (void)hipFree(b->d_iters);
+    if (b->d_err) (void)hipFree(b->d_err);
+    if (b->d_done) (void)hipFree(b->d_done);
+    delete b;
+}
+
+static float *plane_ptr(faldoi_tvl1_batch *b, int pair, int plane)
+{
+    return b->slabs + ((size_t)pair * P_COUNT + plane) * b->plane_elems;
+}
+
+extern "C" int faldoi_tvl1_batch_upload(faldoi_tvl1_batch *b, int pair, const float *I0, const float *I1,
+                                        const float *u, const float *xi)
+{
+    if (!b || !I0 || !I1 || !u) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    if (pair < 0 || pair >= b->npairs) return fail(FALDOI_ERR_INVALID, "pair %d out of range", pair);
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t s = b->ctx->stream;
+    const size_t n = (size_t)b->nx * b->ny, nb = n * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(plane_ptr(b, pair, P_I0), I0, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(plane_ptr(b, pair, P_I1), I1, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(plane_ptr(b, pair, P_INIT + 0), u, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(plane_ptr(b, pair, P_INIT + 1), u + n, nb, hipMemcpyHostToDevice, s));
+    for (int k = 0; k < 4; ++k) {
+        if (xi)
+            HIP_TRY(hipMemcpyAsync(plane_ptr(b, pair, P_INIT + 2 + k), xi + k * n, nb, hipMemcpyHostToDevice, s));
+        else
+            HIP_TRY(hipMemsetAsync(plane_ptr(b, pair, P_INIT + 2 + k), 0, nb, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    b->uploaded[pair] = 1;
+    b->solved = false;
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_tvl1_batch_reset(faldoi_tvl1_batch *b)
+{
+    if (!b) return fail(FALDOI_ERR_INVALID, "batch is NULL");
+    b->solved = false;      // batch_solve always restarts from the uploaded state
+    return FALDOI_OK;
+}
+
+static int ensure(void **p, size_t *have, size_t want_bytes)
+{
+    if (*p && *have >= want_bytes) return FALDOI_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(p, want_bytes));
+    *have = want_bytes;
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, faldoi_tvl1_stats *stats)
+{
+    if (!b || !prm) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < b->npairs; ++i)
+        if (!b->uploaded[i]) return fail(FALDOI_ERR_STATE, "pair %d was never uploaded", i);
+    if (!(prm->lambda > 0) || !(prm->theta > 0) || !(prm->tau > 0) || !(prm->tol >= 0))
+        return fail(FALDOI_ERR_INVALID, "lambda/theta/tau must be > 0 and tol >= 0");
+    if (prm->warps < 1 || prm->warps > 100000) return fail(FALDOI_ERR_INVALID, "warps=%d outside 1..100000", prm->warps);
+    if (prm->max_inner < 1 || prm->max_inner > 1000000)
+        return fail(FALDOI_ERR_INVALID, "max_inner=%d outside 1..1000000", prm->max_inner);
+    if (prm->chunk < 0 || prm->chunk > FALDOI_MAX_CHUNK)
+        return fail(FALDOI_ERR_INVALID, "chunk=%d outside 0..%d", prm->chunk, FALDOI_MAX_CHUNK);
+
+    faldoi_ctx *c = b->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const TileCfg tc = pick_tile();
+    const int TH = tc.R * tc.NW;
+    int chunk = prm->chunk ? prm->chunk : 10;
+    if (chunk > prm->max_inner) chunk = prm->max_inner;
+    while (chunk > 1 && TH - 2 * chunk < 8) --chunk;       // keep a useful tile interior
+    const int halo = chunk;
+    const int Sx = kTileW - 2 * halo, Sy = TH - 2 * halo;
+    const int ntx = (b->nx + Sx - 1) / Sx, nty = (b->ny + Sy - 1) / Sy;
+    const int ntiles = ntx * nty;
+    const int total_tiles = ntiles * b->npairs;
+    const dim3 grid(8 * ((total_tiles + 7) / 8));
+    const int warps = prm->warps;
+    const bool dynamic = prm->tol_stop != 0;
+
+    TvConst k;
+    k.l_t = prm->lambda * prm->theta;          // src/global_faldoi.cpp:577
+    k.theta = prm->theta;
+    k.tau = prm->tau;
+    k.tol2 = prm->tol * prm->tol;              // :684
+    k.max_inner = prm->max_inner;
+    k.tol_stop = prm->tol_stop;
+    k.warps = warps;
+    k.chunk = chunk;
+
+    // workspaces
+    {
+        const size_t slots = dynamic ? 1 : (size_t)warps;
+        size_t have = b->err_part_elems * sizeof(float);
+        int rc = ensure((void **)&b->err_part, &have, slots * total_tiles * kMaxChunk * sizeof(float));
+        if (rc) return rc;
+        b->err_part_elems = have / sizeof(float);
+        if (b->stats_cap < warps * b->npairs) {
+            if (b->d_iters) (void)hipFree(b->d_iters);
+            if (b->d_err) (void)hipFree(b->d_err);
+            b->d_iters = nullptr;
+            b->d_err = nullptr;
+            b->stats_cap = 0;
+            HIP_TRY(hipMalloc((void **)&b->d_iters, sizeof(int) * warps * b->npairs));
+            HIP_TRY(hipMalloc((void **)&b->d_err, sizeof(float) * warps * b->npairs));
+            b->stats_cap = warps * b->npairs;
+        }
+    }
+
+    const int npix = b->nx * b->ny;
+    int launches = 0;
+    HIP_TRY(hipEventRecord(c->ev0, s));
+    HIP_TRY(hipMemsetAsync(b->d_done, 0, sizeof(int), s));
+    {
+        const int blocks = (int)(((size_t)npix * b->npairs + 255) / 256);
+        hipLaunchKernelGGL(reset_state_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, b->slabs,
+                           b->plane_elems, npix, b->npairs, b->ctl, chunk);
+        HIP_TRY(hipGetLastError());
+        // src/global_faldoi.cpp:611: centred gradient of I1, once per solve
+        hipLaunchKernelGGL(centered_gradient_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s,
+                           plane_ptr(b, 0, P_I1), plane_ptr(b, 0, P_I1X), plane_ptr(b, 0, P_I1Y), b->nx, b->ny,
+                           (size_t)P_COUNT * b->plane_elems, (size_t)P_COUNT * b->plane_elems, b->npairs);
+        HIP_TRY(hipGetLastError());
+    }
+
+    if (!dynamic) {
+        int cur = 0;
+        int last_iters = chunk;
+        for (int w = 0; w < warps; ++w) {
+            int n = 0;
+            while (n < prm->max_inner) {
+                const int it = (prm->max_inner - n) < chunk ? (prm->max_inner - n) : chunk;
+                HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
+                                     b->ctl, b->err_part, 1, cur, n == 0, it, w));
+                ++launches;
+                cur ^= 1;
+                n += it;
+                last_iters = it;
+            }
+        }
+        hipLaunchKernelGGL(tvl1_static_stats_kernel, dim3(warps * b->npairs), dim3(256), 0, s, b->err_part, ntiles,
+                           b->npairs, warps, prm->max_inner, last_iters, b->d_iters, b->d_err);
+        HIP_TRY(hipGetLastError());
+        for (int i = 0; i < b->npairs; ++i) b->final_cur[i] = cur;
+    } else {
+        int group = 8;
+        if (const char *g = getenv("FALDOI_SYNC_GROUP")) { int v = atoi(g); if (v >= 1 && v <= 1024) group = v; }
+        const long max_launches = 2L * warps * ((prm->max_inner + chunk - 1) / chunk + 1) + group;
+        for (;;) {
+            for (int g = 0; g < group; ++g) {
+                HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
+                                     b->ctl, b->err_part, 0, 0, 0, 0, 0));
+                hipLaunchKernelGGL(tvl1_ctl_kernel, dim3(b->npairs), dim3(256), 0, s, b->ctl, b->err_part, ntiles, k,
+                                   b->d_iters, b->d_err, b->d_done);
+                HIP_TRY(hipGetLastError());
+                ++launches;
+            }
+            HIP_TRY(hipMemcpyAsync(c->h_done, b->d_done, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (*c->h_done >= b->npairs) break;
+            if (launches > max_launches) return fail(FALDOI_ERR_STATE, "solver state machine did not terminate");
+        }
+        std::vector<PairCtl> hc(b->npairs);
+        HIP_TRY(hipMemcpyAsync(hc.data(), b->ctl, sizeof(PairCtl) * b->npairs, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int i = 0; i < b->npairs; ++i) b->final_cur[i] = hc[i].cur;
+    }
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+
+    std::vector<int> h_it((size_t)warps * b->npairs);
+    std::vector<float> h_er((size_t)warps * b->npairs);
+    HIP_TRY(hipMemcpy(h_it.data(), b->d_iters, sizeof(int) * h_it.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_er.data(), b->d_err, sizeof(float) * h_er.size(), hipMemcpyDeviceToHost));
+    long px_iters = 0;
+    for (int i = 0; i < b->npairs; ++i) {
+        long tot = 0;
+        for (int w = 0; w < warps; ++w) tot += h_it[(size_t)i * warps + w];
+        px_iters += tot * (long)npix;
+        if (stats) {
+            faldoi_tvl1_stats *st = &stats[i];
+            st->total_iters = tot;
+            st->solve_ms = ms;
+            st->chunk_launches = launches;
+            const int nrep = warps < st->iters_cap ? warps : st->iters_cap;
+            st->warps = nrep;
+            for (int w = 0; w < nrep; ++w) {
+                if (st->iters) st->iters[w] = h_it[(size_t)i * warps + w];
+                if (st->err) st->err[w] = h_er[(size_t)i * warps + w];
+            }
+        }
+        if (prm->verbose)
+            for (int w = 0; w < warps; ++w)      // same text as src/global_faldoi.cpp:803
+                fprintf(stderr, "Warping: %d,Iter: %d Error: %f\n", w, h_it[(size_t)i * warps + w],
+                        h_er[(size_t)i * warps + w]);
+    }
+    b->solved = true;
+    b->last_ms = ms;
+    b->last_launches = launches;
+    b->last_px_iters = px_iters;
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *chunk_launches, long *px_iters)
+{
+    if (!b) return fail(FALDOI_ERR_INVALID, "batch is NULL");
+    if (!b->solved) return fail(FALDOI_ERR_STATE, "no solve has completed");
+    if (solve_ms) *solve_ms = b->last_ms;
+    if (chunk_launches) *chunk_launches = b->last_launches;
+    if (px_iters) *px_iters = b->last_px_iters;
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_tvl1_batch_download(faldoi_tvl1_batch *b, int pair, float *u, float *xi)
+{
+    if (!b || !u) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    if (pair < 0 || pair >= b->npairs) return fail(FALDOI_ERR_INVALID, "pair %d out of range", pair);
+    if (!b->solved) return fail(FALDOI_ERR_STATE, "download before solve");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t s = b->ctx->stream;
+    const size_t n = (size_t)b->nx * b->ny, nb = n * sizeof(float);
+    const int st = b->final_cur[pair] ? P_STATE1 : P_STATE0;
+    HIP_TRY(hipMemcpyAsync(u, plane_ptr(b, pair, st + 0), nb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(u + n, plane_ptr(b, pair, st + 1), nb, hipMemcpyDeviceToHost, s));
+    if (xi)
+        for (int k = 0; k < 4; ++k)
+            HIP_TRY(hipMemcpyAsync(xi + k * n, plane_ptr(b, pair, st + 4 + k), nb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return FALDOI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ one-call solver
+extern "C" int faldoi_tvl1_global(faldoi_ctx *ctx, const float *I0, const float *I1, float *u, float *xi, int nx, int ny,
+                                  const faldoi_tvl1_params *prm, faldoi_tvl1_stats *stats)
+{
+    if (!ctx || !I0 || !I1 || !u || !prm) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    faldoi_tvl1_batch *b = nullptr;
+    int rc = faldoi_tvl1_batch_create(ctx, 1, nx, ny, &b);
+    if (rc) return rc;
+    rc = faldoi_tvl1_batch_upload(b, 0, I0, I1, u, xi);
+    if (!rc) rc = faldoi_tvl1_batch_solve(b, prm, stats);
+    if (!rc) rc = faldoi_tvl1_batch_download(b, 0, u, xi);
+    faldoi_tvl1_batch_destroy(b);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------ primitives
+namespace {
+struct DevBuf {
+    float *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+static int prim_check(faldoi_ctx *ctx, int nx, int ny)
+{
+    if (!ctx) return fail(FALDOI_ERR_INVALID, "ctx is NULL");
+    if (nx < 2 || ny < 2 || (long)nx * ny > (1L << 28)) return fail(FALDOI_ERR_INVALID, "image size %dx%d unsupported", nx, ny);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return FALDOI_OK;
+}
+
+// Runs `launch(d_in[0..nin), d_out[0..nout))` on device copies of the host planes.
+template <typename F>
+static int run_planes(faldoi_ctx *ctx, int nx, int ny, const float *const *in, int nin, float *const *out, int nout, F launch)
+{
+    int rc = prim_check(ctx, nx, ny);
+    if (rc) return rc;
+    for (int i = 0; i < nin; ++i) if (!in[i]) return fail(FALDOI_ERR_INVALID, "NULL input plane");
+    for (int i = 0; i < nout; ++i) if (!out[i]) return fail(FALDOI_ERR_INVALID, "NULL output plane");
+    const size_t n = (size_t)nx * ny, nb = n * sizeof(float);
+    DevBuf buf;
+    HIP_TRY(hipMalloc((void **)&buf.p, nb * (nin + nout)));
+    float *d_in[4], *d_out[4];
+    for (int i = 0; i < nin; ++i) {
+        d_in[i] = buf.p + i * n;
+        HIP_TRY(hipMemcpyAsync(d_in[i], in[i], nb, hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (int i = 0; i < nout; ++i) d_out[i] = buf.p + (nin + i) * n;
+    const int blocks = (int)((n + 255) / 256);
+    launch(dim3(blocks < 4096 ? blocks : 4096), dim3(256), ctx->stream, d_in, d_out);
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < nout; ++i) HIP_TRY(hipMemcpyAsync(out[i], d_out[i], nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_centered_gradient(faldoi_ctx *ctx, const float *in, float *dx, float *dy, int nx, int ny)
+{
+    const float *ins[1] = {in};
+    float *outs[2] = {dx, dy};
+    return run_planes(ctx, nx, ny, ins, 1, outs, 2, [&](dim3 g, dim3 b, hipStream_t s, float **i, float **o) {
+        hipLaunchKernelGGL(centered_gradient_kernel, g, b, 0, s, i[0], o[0], o[1], nx, ny, (size_t)0, (size_t)0, 1);
+    });
+}
+
+extern "C" int faldoi_forward_gradient(faldoi_ctx *ctx, const float *f, float *fx, float *fy, int nx, int ny)
+{
+    const float *ins[1] = {f};
+    float *outs[2] = {fx, fy};
+    return run_planes(ctx, nx, ny, ins, 1, outs, 2, [&](dim3 g, dim3 b, hipStream_t s, float **i, float **o) {
+        hipLaunchKernelGGL(forward_gradient_kernel, g, b, 0, s, i[0], o[0], o[1], nx, ny);
+    });
+}
+
+extern "C" int faldoi_divergence(faldoi_ctx *ctx, const float *v1, const float *v2, float *dv, int nx, int ny)
+{
+    const float *ins[2] = {v1, v2};
+    float *outs[1] = {dv};
+    return run_planes(ctx, nx, ny, ins, 2, outs, 1, [&](dim3 g, dim3 b, hipStream_t s, float **i, float **o) {
+        hipLaunchKernelGGL(divergence_kernel, g, b, 0, s, i[0], i[1], o[0], nx, ny);
+    });
+}
+
+extern "C" int faldoi_bicubic_warp(faldoi_ctx *ctx, const float *in, const float *u, const float *v, float *out, int nx,
+                                   int ny, int border_out)
+{
+    const float *ins[3] = {in, u, v};
+    float *outs[1] = {out};
+    return run_planes(ctx, nx, ny, ins, 3, outs, 1, [&](dim3 g, dim3 b, hipStream_t s, float **i, float **o) {
+        hipLaunchKernelGGL(bicubic_warp_kernel, g, b, 0, s, i[0], i[1], i[2], o[0], nx, ny, border_out);
+    });
+}

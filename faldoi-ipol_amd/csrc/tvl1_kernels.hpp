@@ -1,0 +1,457 @@
+// tvl1_kernels.hpp -- HIP kernels of the TV-L1 global minimisation (gfx950 / MI355X).
+//
+// Design: the reference runs seven full-image passes per inner iteration
+// (src/global_faldoi.cpp:690-783, 208 B/px/iteration of traffic).  Here ONE launch advances a
+// tile by up to FALDOI_MAX_CHUNK inner iterations with the whole per-pixel state held in
+// registers (temporal blocking): a workgroup loads its tile plus a halo as wide as the number
+// of iterations, iterates without touching HBM, and writes back only the tile interior, whose
+// values are exactly what the full-image sweeps would have produced.  The halo absorbs the
+// one-pixel-per-iteration growth of the stencil's dependency cone, so workgroups never
+// communicate inside a launch.
+//
+// Lane layout: tile width = 64 = one wavefront; lane l owns column l; wave w owns rows
+// [w*R, w*R+R) of that column in registers.  Horizontal neighbours come from the adjacent
+// lane (wavefront shuffle), vertical neighbours from the thread's own registers, except
+// across wave boundaries where one row per wave is exchanged through LDS.
+#pragma once
+#include "faldoi_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace faldoi {
+
+constexpr int kTileW = 64;          // one wavefront wide
+constexpr int kMaxChunk = 16;       // == FALDOI_MAX_CHUNK
+
+// Plane indices inside one pair's slab (each plane = plane_elems floats).
+enum Plane {
+    P_I0 = 0, P_I1, P_I1X, P_I1Y,            // inputs + centred gradient of I1 (per solve)
+    P_RC, P_IWX, P_IWY,                      // per-warp constants: rho_c, I1wx, I1wy
+    P_STATE0,                                // state buffer 0: u1 u2 ub1 ub2 xi11 xi12 xi21 xi22
+    P_STATE1 = P_STATE0 + 8,                 // state buffer 1 (ping-pong)
+    P_INIT = P_STATE1 + 8,                   // uploaded u1 u2 xi11..xi22 (for batch_reset)
+    P_COUNT = P_INIT + 6
+};
+
+struct TvConst {
+    float l_t, theta, tau, tol2;
+    int max_inner, tol_stop, warps, chunk;
+};
+
+// Per-pair control block, owned by the device between launches in "dynamic" (tolerance stop)
+// mode; in static mode the host passes the same fields as kernel arguments.
+struct PairCtl {
+    int warp;        // current outer warp
+    int n;           // inner iterations completed in this warp
+    int cur;         // which state buffer holds the current state
+    int first;       // next chunk starts a warp (do the bicubic warp, ubar = u)
+    int iters;       // inner iterations the next chunk launch must run (0 = nothing to do)
+    int redo;        // next chunk is the exact-length re-run that ends the warp
+    int done;        // all warps finished
+    int pad;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Small stand-alone kernels (per-solve setup and the C-ABI primitives).
+// ---------------------------------------------------------------------------------------------
+
+// src/utils.cpp:367 centered_gradient.  Grid-stride over pixels of `npairs` planes.
+__global__ void centered_gradient_kernel(const float *__restrict__ in, float *__restrict__ dx,
+                                         float *__restrict__ dy, int nx, int ny,
+                                         size_t in_stride, size_t out_stride, int npairs)
+{
+    const size_t n = (size_t)nx * ny;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n * npairs;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int pair = (int)(i / n);
+        const int p = (int)(i - (size_t)pair * n);
+        const int y = p / nx, x = p - y * nx;
+        const float *I = in + pair * in_stride;
+        const int xl = x > 0 ? x - 1 : x, xr = x < nx - 1 ? x + 1 : x;
+        const int yu = y > 0 ? y - 1 : y, yd = y < ny - 1 ? y + 1 : y;
+        dx[pair * out_stride + p] = centered_diff(I[y * nx + xr], I[y * nx + xl]);
+        dy[pair * out_stride + p] = centered_diff(I[yd * nx + x], I[yu * nx + x]);
+    }
+}
+
+// src/utils.cpp:285 forward_gradient.
+__global__ void forward_gradient_kernel(const float *__restrict__ f, float *__restrict__ fx,
+                                        float *__restrict__ fy, int nx, int ny)
+{
+    const int n = nx * ny;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const int y = p / nx, x = p - y * nx;
+        const float s = f[p];
+        const float r = (x < nx - 1) ? f[p + 1] : 0.0f;
+        const float d = (y < ny - 1) ? f[p + nx] : 0.0f;
+        fx[p] = fwd_diff(r, s, x == nx - 1);
+        fy[p] = fwd_diff(d, s, y == ny - 1);
+    }
+}
+
+// src/utils.cpp:239 divergence.
+__global__ void divergence_kernel(const float *__restrict__ v1, const float *__restrict__ v2,
+                                  float *__restrict__ dv, int nx, int ny)
+{
+    const int n = nx * ny;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const int y = p / nx, x = p - y * nx;
+        const float al = (x > 0) ? v1[p - 1] : 0.0f;
+        const float bu = (y > 0) ? v2[p - nx] : 0.0f;
+        dv[p] = div_sample(v1[p], al, v2[p], bu, classify(x, y, nx, ny));
+    }
+}
+
+// src/bicubic_interpolation.c:245 bicubic_interpolation_warp.
+__global__ void bicubic_warp_kernel(const float *__restrict__ in, const float *__restrict__ u,
+                                    const float *__restrict__ v, float *__restrict__ out,
+                                    int nx, int ny, int border_out)
+{
+    const int n = nx * ny;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const int y = p / nx, x = p - y * nx;
+        const float uu = (float)x + u[p];
+        const float vv = (float)y + v[p];
+        const BicubicTaps t = bicubic_taps(uu, vv, nx, ny);
+        out[p] = (t.clamped && border_out) ? 0.0f : bicubic_eval(in, t, nx);
+    }
+}
+
+// Copies the uploaded initial flow/duals into state buffer 0 and resets the control blocks.
+__global__ void reset_state_kernel(float *__restrict__ base, size_t plane_elems, int npix, int npairs,
+                                   PairCtl *__restrict__ ctl, int first_iters)
+{
+    const size_t total = (size_t)npix * npairs;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int pair = (int)(i / npix);
+        const int p = (int)(i - (size_t)pair * npix);
+        float *slab = base + (size_t)pair * P_COUNT * plane_elems;
+        const float *ini = slab + (size_t)P_INIT * plane_elems;
+        float *st = slab + (size_t)P_STATE0 * plane_elems;
+        st[0 * plane_elems + p] = ini[0 * plane_elems + p];            // u1
+        st[1 * plane_elems + p] = ini[1 * plane_elems + p];            // u2
+#pragma unroll
+        for (int k = 0; k < 4; ++k)                                    // xi11..xi22
+            st[(4 + k) * plane_elems + p] = ini[(2 + k) * plane_elems + p];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < npairs) {
+        PairCtl c;
+        c.warp = 0; c.n = 0; c.cur = 0; c.first = 1; c.iters = first_iters; c.redo = 0; c.done = 0; c.pad = 0;
+        ctl[threadIdx.x] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused kernel: [bicubic warp + per-warp constants] + `iters` primal-dual iterations.
+// ---------------------------------------------------------------------------------------------
+//
+// Grid: 8 * ceil(npairs*ntx*nty / 8) blocks of 64*NW threads.  Blocks are dealt to the 8 XCDs
+// round-robin, so block b -> logical tile (b % 8) * per + b / 8 keeps spatially adjacent tiles
+// (which share halo lines) on one XCD's L2.  Placement only affects speed.
+//
+// Tile (tx,ty) of a pair: origin (tx*Sx - halo, ty*Sy - halo), Sx = 64 - 2*halo,
+// Sy = NW*R - 2*halo; it owns (stores) image pixels [tx*Sx,(tx+1)*Sx) x [ty*Sy,(ty+1)*Sy).
+// After i iterations the values within distance i of a tile edge that is not an image edge are
+// no longer the full-image values; with iters <= halo they never reach the owned region.
+//
+// err_out[(err_slot*ntiles_total + tile_global) * kMaxChunk + i] = max |du|^2 over the owned
+// pixels after iteration i of this launch (plain stores, reduced by tvl1_ctl_kernel).
+template <int R, int NW>
+__global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
+    float *__restrict__ base, size_t plane_elems, int nx, int ny, int ntx, int nty, int npairs,
+    int halo, TvConst prm, const PairCtl *__restrict__ ctl, float *__restrict__ err_out,
+    int static_mode, int s_cur, int s_first, int s_iters, int err_slot)
+{
+    constexpr int TH = R * NW;
+    __shared__ float s_ub1[NW][kTileW];
+    __shared__ float s_ub2[NW][kTileW];
+    __shared__ float s_x12[NW][kTileW];
+    __shared__ float s_x22[NW][kTileW];
+    __shared__ unsigned s_err[kMaxChunk];
+
+    const int per = gridDim.x >> 3;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int ntiles = ntx * nty;
+    if (t >= ntiles * npairs) return;
+    const int pair = t / ntiles;
+    const int tile = t - pair * ntiles;
+    const int tyi = tile / ntx, txi = tile - tyi * ntx;
+
+    int cur, first, iters;
+    if (static_mode) {
+        cur = s_cur; first = s_first; iters = s_iters;
+    } else {
+        const PairCtl c = ctl[pair];
+        cur = c.cur; first = c.first; iters = c.iters;
+    }
+    if (iters <= 0) return;                     // uniform across the block
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int Sx = kTileW - 2 * halo, Sy = TH - 2 * halo;
+    const int gx = txi * Sx - halo + lane;
+    const int gy0 = tyi * Sy - halo + wv * R;
+    const bool col_in = gx >= 0 && gx < nx;
+    const bool col_own = col_in && gx >= txi * Sx && gx < (txi + 1) * Sx;
+
+    float *slab = base + (size_t)pair * P_COUNT * plane_elems;
+    const float *src = slab + (size_t)(cur ? P_STATE1 : P_STATE0) * plane_elems;
+    float *dst = slab + (size_t)(cur ? P_STATE0 : P_STATE1) * plane_elems;
+    float *rcp = slab + (size_t)P_RC * plane_elems;
+    float *iwxp = slab + (size_t)P_IWX * plane_elems;
+    float *iwyp = slab + (size_t)P_IWY * plane_elems;
+
+    float u1[R], u2[R], ub1[R], ub2[R], x11[R], x12[R], x21[R], x22[R], rc[R], ix[R], iy[R];
+    bool in[R], own[R];
+
+    // ---- load (and, at the start of a warp, build the per-warp constants) ----
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = gy0 + r;
+        in[r] = col_in && gy >= 0 && gy < ny;
+        own[r] = in[r] && col_own && gy >= tyi * Sy && gy < (tyi + 1) * Sy;
+        const int p = in[r] ? gy * nx + gx : 0;
+        u1[r] = in[r] ? src[0 * plane_elems + p] : 0.0f;
+        u2[r] = in[r] ? src[1 * plane_elems + p] : 0.0f;
+        x11[r] = in[r] ? src[4 * plane_elems + p] : 0.0f;
+        x12[r] = in[r] ? src[5 * plane_elems + p] : 0.0f;
+        x21[r] = in[r] ? src[6 * plane_elems + p] : 0.0f;
+        x22[r] = in[r] ? src[7 * plane_elems + p] : 0.0f;
+    }
+    if (first) {
+        const float *I0 = slab + (size_t)P_I0 * plane_elems;
+        const float *I1 = slab + (size_t)P_I1 * plane_elems;
+        const float *I1x = slab + (size_t)P_I1X * plane_elems;
+        const float *I1y = slab + (size_t)P_I1Y * plane_elems;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ub1[r] = u1[r];                                     // src/global_faldoi.cpp:659-660
+            ub2[r] = u2[r];
+            rc[r] = 0.0f; ix[r] = 0.0f; iy[r] = 0.0f;
+            if (in[r]) {
+                const int gy = gy0 + r;
+                const int p = gy * nx + gx;
+                const float uu = (float)gx + u1[r];             // src/bicubic_interpolation.c:259-260
+                const float vv = (float)gy + u2[r];
+                const BicubicTaps tp = bicubic_taps(uu, vv, nx, ny);
+                float w0 = 0.0f, wx = 0.0f, wy = 0.0f;          // border_out = true (:635-637)
+                if (!tp.clamped) {
+                    w0 = bicubic_eval(I1, tp, nx);
+                    wx = bicubic_eval(I1x, tp, nx);
+                    wy = bicubic_eval(I1y, tp, nx);
+                }
+                ix[r] = wx;
+                iy[r] = wy;
+                rc[r] = rho_const(w0, wx, wy, u1[r], u2[r], I0[p]);
+                if (own[r]) {                                   // later chunks of this warp reload them
+                    rcp[p] = rc[r];
+                    iwxp[p] = wx;
+                    iwyp[p] = wy;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = in[r] ? (gy0 + r) * nx + gx : 0;
+            ub1[r] = in[r] ? src[2 * plane_elems + p] : 0.0f;
+            ub2[r] = in[r] ? src[3 * plane_elems + p] : 0.0f;
+            rc[r] = in[r] ? rcp[p] : 0.0f;
+            ix[r] = in[r] ? iwxp[p] : 0.0f;
+            iy[r] = in[r] ? iwyp[p] : 0.0f;
+        }
+    }
+
+    if (threadIdx.x < kMaxChunk) s_err[threadIdx.x] = 0u;
+    s_ub1[wv][lane] = ub1[0];
+    s_ub2[wv][lane] = ub2[0];
+
+    const bool last_c = (gx == nx - 1);
+    const bool first_c = (gx == 0);
+
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();                                       // ubar row 0 of every wave visible
+        // ---- dual step: forward gradient of ubar (:725-726) + ofTVl2_getD (:735) ----
+        const float dn1 = (wv < NW - 1) ? s_ub1[wv + 1][lane] : 0.0f;
+        const float dn2 = (wv < NW - 1) ? s_ub2[wv + 1][lane] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = gy0 + r;
+            const float r1 = __shfl_down(ub1[r], 1);
+            const float r2 = __shfl_down(ub2[r], 1);
+            const float d1 = (r < R - 1) ? ub1[r < R - 1 ? r + 1 : r] : dn1;
+            const float d2 = (r < R - 1) ? ub2[r < R - 1 ? r + 1 : r] : dn2;
+            const bool last_r = (gy == ny - 1);
+            dual_step(x11[r], x12[r], x21[r], x22[r],
+                      fwd_diff(r1, ub1[r], last_c), fwd_diff(d1, ub1[r], last_r),
+                      fwd_diff(r2, ub2[r], last_c), fwd_diff(d2, ub2[r], last_r), prm.tau);
+        }
+        s_x12[wv][lane] = x12[R - 1];
+        s_x22[wv][lane] = x22[R - 1];
+        __syncthreads();                                       // new duals' last rows visible
+        // ---- primal step: divergence (:745-746), TH (:690-718), getP (:770), relax (:780) ----
+        const float up12 = (wv > 0) ? s_x12[wv - 1][lane] : 0.0f;
+        const float up22 = (wv > 0) ? s_x22[wv - 1][lane] : 0.0f;
+        float emax = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = gy0 + r;
+            const PixClass pc{ first_c, last_c, gy == 0, gy == ny - 1 };
+            const float l11 = __shfl_up(x11[r], 1);
+            const float l21 = __shfl_up(x21[r], 1);
+            const float t12 = (r > 0) ? x12[r > 0 ? r - 1 : 0] : up12;
+            const float t22 = (r > 0) ? x22[r > 0 ? r - 1 : 0] : up22;
+            const float div1 = div_sample(x11[r], l11, x12[r], t12, pc);
+            const float div2 = div_sample(x21[r], l21, x22[r], t22, pc);
+            float v1, v2;
+            threshold_step(rc[r], ix[r], iy[r], grad_sq(ix[r], iy[r]), u1[r], u2[r], prm.l_t, v1, v2);
+            const float e = primal_step(u1[r], u2[r], ub1[r], ub2[r], v1, v2, div1, div2, prm.theta, prm.tau);
+            emax = (own[r] && e > emax) ? e : emax;
+        }
+        s_ub1[wv][lane] = ub1[0];
+        s_ub2[wv][lane] = ub2[0];
+        // max over the wavefront, then one LDS atomic per wave (order-independent => deterministic)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(emax, o);
+            emax = other > emax ? other : emax;
+        }
+        if (lane == 0) atomicMax(&s_err[it], __float_as_uint(emax));
+    }
+
+    // ---- store the owned interior into the other state buffer ----
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (own[r]) {
+            const int p = (gy0 + r) * nx + gx;
+            dst[0 * plane_elems + p] = u1[r];
+            dst[1 * plane_elems + p] = u2[r];
+            dst[2 * plane_elems + p] = ub1[r];
+            dst[3 * plane_elems + p] = ub2[r];
+            dst[4 * plane_elems + p] = x11[r];
+            dst[5 * plane_elems + p] = x12[r];
+            dst[6 * plane_elems + p] = x21[r];
+            dst[7 * plane_elems + p] = x22[r];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxChunk) {
+        const size_t slot = (size_t)err_slot * ntiles * npairs + t;
+        err_out[slot * kMaxChunk + threadIdx.x] =
+            (threadIdx.x < iters) ? __uint_as_float(s_err[threadIdx.x]) : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Control kernel (dynamic mode): one block per pair, run after every chunk launch.
+// Reduces the per-tile error maxima and advances the pair's state machine exactly like the
+// reference's loop control  `while (err_D > tol*tol && n < MAX_ITERATIONS_GLOBAL)`
+// (src/global_faldoi.cpp:684) and `for warpings < warps` (:631).
+// iters_out/err_out: [npairs][warps] -- what the reference prints at :803.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tvl1_ctl_kernel(PairCtl *__restrict__ ctl, const float *__restrict__ err_part,
+                                                       int ntiles, TvConst prm, int *__restrict__ iters_out,
+                                                       float *__restrict__ err_out, int *__restrict__ done_count)
+{
+    __shared__ float s_e[kMaxChunk][256];
+    const int pair = blockIdx.x;
+    PairCtl c = ctl[pair];
+    if (c.done || c.iters <= 0) return;
+
+    // e[i] = max over this pair's tiles of the tile maxima (values are >= 0; max is exact)
+    float loc[kMaxChunk];
+#pragma unroll
+    for (int i = 0; i < kMaxChunk; ++i) loc[i] = 0.0f;
+    const float *ep = err_part + (size_t)pair * ntiles * kMaxChunk;
+    for (int tl = threadIdx.x; tl < ntiles; tl += blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < kMaxChunk; ++i) {
+            const float v = ep[(size_t)tl * kMaxChunk + i];
+            loc[i] = v > loc[i] ? v : loc[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxChunk; ++i) s_e[i][threadIdx.x] = loc[i];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) {
+                const float a = s_e[i][threadIdx.x], b = s_e[i][threadIdx.x + s];
+                s_e[i][threadIdx.x] = b > a ? b : a;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+
+    // first iteration of this chunk after which the reference's while-condition fails
+    int stop_at = -1;
+    if (prm.tol_stop && !c.redo) {
+        for (int i = 0; i < c.iters; ++i)
+            if (!(s_e[i][0] > prm.tol2)) { stop_at = i; break; }
+    }
+    bool warp_ends = false;
+    if (stop_at >= 0 && stop_at < c.iters - 1) {
+        // stopped inside the chunk: re-run the same input for exactly stop_at+1 iterations
+        c.redo = 1;
+        c.iters = stop_at + 1;
+    } else {
+        c.n += c.iters;
+        const float e_last = s_e[c.iters - 1][0];
+        warp_ends = c.redo || stop_at >= 0 || c.n >= prm.max_inner;
+        c.cur ^= 1;
+        c.redo = 0;
+        if (warp_ends) {
+            iters_out[pair * prm.warps + c.warp] = c.n;
+            err_out[pair * prm.warps + c.warp] = e_last;
+            c.warp += 1;
+            c.n = 0;
+            c.first = 1;
+        } else {
+            c.first = 0;
+        }
+        if (c.warp >= prm.warps) {
+            c.done = 1;
+            c.iters = 0;
+            atomicAdd(done_count, 1);
+        } else {
+            const int left = prm.max_inner - c.n;
+            c.iters = left < prm.chunk ? left : prm.chunk;
+        }
+    }
+    ctl[pair] = c;
+}
+
+// Static mode epilogue: per-warp error = max over tiles of the last iteration's tile maxima.
+// err_part: [warps][npairs*ntiles][kMaxChunk]; last_iters = iterations of the warp's last chunk.
+__global__ __launch_bounds__(256) void tvl1_static_stats_kernel(const float *__restrict__ err_part, int ntiles,
+                                                                int npairs, int warps, int max_inner, int last_iters,
+                                                                int *__restrict__ iters_out, float *__restrict__ err_out)
+{
+    __shared__ float s_e[256];
+    const int pair = blockIdx.x % npairs;
+    const int w = blockIdx.x / npairs;
+    const float *ep = err_part + ((size_t)w * npairs + pair) * ntiles * kMaxChunk;
+    float m = 0.0f;
+    for (int tl = threadIdx.x; tl < ntiles; tl += blockDim.x) {
+        const float v = ep[(size_t)tl * kMaxChunk + (last_iters - 1)];
+        m = v > m ? v : m;
+    }
+    s_e[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const float b = s_e[threadIdx.x + s];
+            if (b > s_e[threadIdx.x]) s_e[threadIdx.x] = b;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        iters_out[pair * warps + w] = max_inner;
+        err_out[pair * warps + w] = s_e[0];
+    }
+}
+
+}  // namespace faldoi

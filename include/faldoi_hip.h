@@ -1,0 +1,137 @@
+/*
+ * faldoi_hip.h -- C ABI of libfaldoi_hip.so: the MI355X (gfx950) implementation of FALDOI's
+ * dense variational minimisation hot path.
+ *
+ * The reference (fperezgamonal/faldoi-ipol) has no FFI/plugin ABI; its de-facto operator
+ * surface is a set of C++ functions called in-process.  Each entry point
+ * below names the reference function it replaces (file:line in the upstream repo) and keeps
+ * its argument meaning: planar row-major fp32 images, caller-owned host buffers, flow stored
+ * as two contiguous planes (u1 then u2), dual variables xi caller-zeroed and updated in place.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (FALDOI_OK == 0) and never
+ *     throws or aborts (the reference's void functions abort()/assert on failure);
+ *   - a faldoi_ctx owns one device + one HIP stream + workspaces; distinct contexts may be used
+ *     from distinct host threads, one context is not thread-safe (mirrors the reference's
+ *     per-thread SpecificOFStuff/OpticalFlowData ownership, src/local_faldoi.cpp:1192-1219);
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point returns
+ *     FALDOI_ERR_NO_DEVICE.
+ */
+#ifndef FALDOI_HIP_H
+#define FALDOI_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FALDOI_ABI_VERSION 1
+
+enum {
+    FALDOI_OK = 0,
+    FALDOI_ERR_INVALID = 1,      /* bad argument (null pointer, size, parameter range) */
+    FALDOI_ERR_NO_DEVICE = 2,    /* no HIP device / device index out of range */
+    FALDOI_ERR_HIP = 3,          /* a HIP runtime call failed; see faldoi_last_error() */
+    FALDOI_ERR_OOM = 4,          /* device or host allocation failed */
+    FALDOI_ERR_STATE = 5         /* call sequence error (e.g. solve before upload) */
+};
+
+/* Reference constants, src/parameters.h:20-22,31,43,51 */
+#define FALDOI_DEFAULT_LAMBDA 40.0f
+#define FALDOI_DEFAULT_THETA 0.3f
+#define FALDOI_DEFAULT_TAU 0.125f
+#define FALDOI_DEFAULT_TOL 0.01f
+#define FALDOI_DEFAULT_MAX_INNER 400
+#define FALDOI_DEFAULT_WARPS_GLOBAL 5
+#define FALDOI_MAX_CHUNK 16        /* inner iterations fused into one launch (halo width) */
+
+typedef struct faldoi_ctx faldoi_ctx;
+typedef struct faldoi_tvl1_batch faldoi_tvl1_batch;
+
+/* Solver parameters: the scalar arguments of tvl2OF (src/global_faldoi.cpp:565-572) plus the
+ * two knobs the reference hard-codes (loop bound MAX_ITERATIONS_GLOBAL and the tolerance stop,
+ * src/global_faldoi.cpp:684) and one scheduling knob of this implementation. */
+typedef struct faldoi_tvl1_params {
+    float lambda;      /* data weight                               (ref default 40)    */
+    float theta;       /* coupling                                  (ref default 0.3)   */
+    float tau;         /* time step                                 (ref default 0.125) */
+    float tol;         /* stop when max|du|^2 <= tol*tol            (ref default 0.01)  */
+    int warps;         /* outer warps                               (ref default 5)     */
+    int max_inner;     /* inner iteration bound per warp            (ref: 400)          */
+    int tol_stop;      /* 1 = reference behaviour; 0 = always run max_inner iterations  */
+    int chunk;         /* inner iterations per kernel launch, 1..FALDOI_MAX_CHUNK; 0 = auto.
+                          Affects speed only: results are bit-identical for every value. */
+    int verbose;       /* 1 = print the reference's "Warping: w,Iter: n Error: e" lines  */
+} faldoi_tvl1_params;
+
+/* What the reference prints per warp (src/global_faldoi.cpp:803) plus timing. */
+typedef struct faldoi_tvl1_stats {
+    long total_iters;        /* sum over warps of inner iterations executed              */
+    int warps;               /* number of valid entries below (min(params.warps, cap))   */
+    int iters_cap;           /* capacity of iters/err given by the caller                */
+    int *iters;              /* caller-owned, may be NULL                                */
+    float *err;              /* caller-owned, may be NULL                                */
+    double solve_ms;         /* device time of the solve (HIP events on the ctx stream)  */
+    int chunk_launches;      /* launches of the fused iteration kernel                   */
+} faldoi_tvl1_stats;
+
+/* ---------------------------------------------------------------- context */
+int faldoi_abi_version(void);
+int faldoi_device_count(int *count);
+int faldoi_ctx_create(int device, faldoi_ctx **out);
+void faldoi_ctx_destroy(faldoi_ctx *ctx);
+int faldoi_ctx_synchronize(faldoi_ctx *ctx);
+/* Thread-local text of the last failure (HIP error string, argument that was rejected). */
+const char *faldoi_last_error(void);
+void faldoi_tvl1_default_params(faldoi_tvl1_params *p);
+
+/* ---------------------------------------------------------------- one-call solver
+ * Replaces  void tvl2OF(const float *I0, float *I1, float *u1, float *u2, float *xi11, float *xi12,
+ *                       float *xi21, float *xi22, lambda, theta, tau, tol_OF, nx, ny, warps, verbose)
+ *           src/global_faldoi.cpp:556-882.
+ * I0,I1: preprocessed gray planes (nx*ny).  u: 2*nx*ny, in = initial flow, out = refined flow.
+ * xi: 4*nx*ny (xi11,xi12,xi21,xi22), in/out; NULL means "all zero, do not return".
+ * Host pointers.  H2D/D2H copies are outside stats->solve_ms. */
+int faldoi_tvl1_global(faldoi_ctx *ctx, const float *I0, const float *I1, float *u, float *xi,
+                       int nx, int ny, const faldoi_tvl1_params *prm, faldoi_tvl1_stats *stats);
+
+/* ---------------------------------------------------------------- device-resident batch
+ * The same solver on `npairs` independent image pairs of one size, all planes resident in HBM
+ * between calls (one batched launch sequence; pairs may stop at different iterations).
+ * This is the form bench.py times and the multi-GPU driver shards (pairs are independent,
+ * SURVEY.md section 8e).  */
+int faldoi_tvl1_batch_create(faldoi_ctx *ctx, int npairs, int nx, int ny, faldoi_tvl1_batch **out);
+void faldoi_tvl1_batch_destroy(faldoi_tvl1_batch *b);
+/* Host -> HBM.  xi may be NULL (zero).  Resets the pair's state. */
+int faldoi_tvl1_batch_upload(faldoi_tvl1_batch *b, int pair, const float *I0, const float *I1,
+                             const float *u, const float *xi);
+/* Restore the flow/duals uploaded last (device-to-device), so a solve can be repeated. */
+int faldoi_tvl1_batch_reset(faldoi_tvl1_batch *b);
+/* Runs the whole solve for every pair; stats may be NULL or an array of npairs entries. */
+int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm,
+                            faldoi_tvl1_stats *stats);
+/* HBM -> host.  u: 2*nx*ny; xi: 4*nx*ny or NULL. */
+int faldoi_tvl1_batch_download(faldoi_tvl1_batch *b, int pair, float *u, float *xi);
+/* Device time (ms) and launch count of the fused iteration kernel accumulated by the last
+ * batch_solve, measured with HIP events on the context's stream around every launch group. */
+int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *chunk_launches,
+                                  long *px_iters);
+
+/* ---------------------------------------------------------------- primitives (host buffers)
+ * Stand-alone launches of the device functions the fused kernel is made of, for stage-level
+ * parity tests and for callers on either side of the hot path. */
+/* src/utils.cpp:367 centered_gradient */
+int faldoi_centered_gradient(faldoi_ctx *ctx, const float *in, float *dx, float *dy, int nx, int ny);
+/* src/utils.cpp:285 forward_gradient */
+int faldoi_forward_gradient(faldoi_ctx *ctx, const float *f, float *fx, float *fy, int nx, int ny);
+/* src/utils.cpp:239 divergence */
+int faldoi_divergence(faldoi_ctx *ctx, const float *v1, const float *v2, float *div, int nx, int ny);
+/* src/bicubic_interpolation.c:245 bicubic_interpolation_warp */
+int faldoi_bicubic_warp(faldoi_ctx *ctx, const float *in, const float *u, const float *v, float *out,
+                        int nx, int ny, int border_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FALDOI_HIP_H */

@@ -1,0 +1,80 @@
+/*
+ * faldoi_oracle.h -- CPU restatement of the FALDOI TV-L1 hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under faldoi-ipol_amd/ (the product) may include,
+ * link or dlopen this.  Allowed users: tests/, __graft_entry__.smoke(), and bench.py's
+ * cpu_baseline leg -- and there only as the checker / the timed CPU baseline.
+ *
+ * Every function states the reference file:line whose arithmetic it restates
+ * (paths relative to the upstream repo fperezgamonal/faldoi-ipol).  The restatement is
+ * written from the algorithm description, with a different loop
+ * structure (per-pixel case analysis, fused passes), but the per-pixel floating-point
+ * expression trees are the reference's, so results are bit-identical when compiled
+ * with -ffp-contract=off on an SSE2 (FLT_EVAL_METHOD 0) target.
+ *
+ * Parity pin status: see oracle/README.md (per-primitive against oracle/_ref built
+ * from the reference's own sources; whole-solver against the known-answer values the
+ * survey recorded from the compiled reference).
+ */
+#ifndef FALDOI_ORACLE_H
+#define FALDOI_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- stencils (src/utils.cpp:239-423, duplicated in src/mask.c:39-240) ---- */
+void orc_centered_gradient(const float *in, float *dx, float *dy, int nx, int ny);
+void orc_forward_gradient(const float *f, float *fx, float *fy, int nx, int ny);
+void orc_divergence(const float *v1, const float *v2, float *div, int nx, int ny);
+
+/* ---- bicubic (src/bicubic_interpolation.c:26-40,103-266) ---- */
+float orc_bicubic_at(const float *in, float uu, float vv, int nx, int ny, int border_out);
+void orc_bicubic_warp(const float *in, const float *u, const float *v, float *out,
+                      int nx, int ny, int border_out);
+
+/* ---- preprocessing (src/global_faldoi.cpp:1820-1828,2053-2068; src/utils.cpp:521-630,679-781) ---- */
+void orc_rgb2gray(const float *rgb_planar, int w, int h, float *out);
+void orc_getminmax(float *mn, float *mx, const float *x, int n);
+void orc_image_normalization_3(const float *I1, const float *I2, const float *I0,
+                               float *I1n, float *I2n, float *I0n, int size);
+void orc_image_normalization_2(const float *I0, const float *I1, float *I0n, float *I1n, int size);
+void orc_gaussian(float *I, int xdim, int ydim, float sigma);
+/* normalised half-kernel B[0..size) as src/utils.cpp:529-552 builds it; returns size */
+int orc_gaussian_taps(float sigma, float *B, int maxn);
+/* gray -> normalise_3 -> gaussian(0.9) exactly as global_faldoi's main does before the solver.
+ * i0,i1,im1: planar images with pd channels (pd==1 or 3), values 0..255.  Outputs w*h each. */
+void orc_preprocess_global(const float *i0, const float *i1, const float *im1, int w, int h, int pd,
+                           float *i0n, float *i1n, float *im1n);
+
+/* ---- TV-L1 global solver (src/global_faldoi.cpp:307-381,556-882) ----
+ * Exactly tvl2OF's arithmetic and loop control, with two additive knobs that default to the
+ * reference's behaviour: max_inner (reference: MAX_ITERATIONS_GLOBAL = 400) and tol_stop
+ * (reference: 1 = stop when max|du|^2 <= tol^2).  iters_out[warps] / err_out[warps] receive the
+ * numbers the reference prints on its "Warping: w,Iter: n Error: e" line.
+ * Returns the total number of inner iterations executed. */
+long orc_tvl1_global(const float *I0, const float *I1, float *u1, float *u2,
+                     float *xi11, float *xi12, float *xi21, float *xi22,
+                     float lambda, float theta, float tau, float tol,
+                     int nx, int ny, int warps, int max_inner, int tol_stop,
+                     int *iters_out, float *err_out);
+
+/* One inner iteration on caller-held planes (used by per-stage parity tests).
+ * Inputs rho_c,I1wx,I1wy,grad are the per-warp constants; u,ubar,xi are updated in place.
+ * Returns max_p |du|^2. */
+float orc_tvl1_iteration(const float *rho_c, const float *I1wx, const float *I1wy, const float *grad,
+                         float *u1, float *u2, float *ub1, float *ub2,
+                         float *xi11, float *xi12, float *xi21, float *xi22,
+                         float lambda, float theta, float tau, int nx, int ny);
+
+/* Per-warp constants (src/global_faldoi.cpp:635-657): 3 bicubic warps (border_out=true) + grad, rho_c. */
+void orc_tvl1_warp_constants(const float *I0, const float *I1, const float *I1x, const float *I1y,
+                             const float *u1, const float *u2,
+                             float *I1wx, float *I1wy, float *grad, float *rho_c, int nx, int ny);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+"""ctypes bindings for the test-only CPU checker (oracle/liboracle.so, oracle/_ref/libfaldoi_ref.so).
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_F = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_I = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref when the reference sources are present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(
+            os.path.join(_HERE, "faldoi_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_centered_gradient.argtypes = [_F, _F, _F, C.c_int, C.c_int]
+        L.orc_forward_gradient.argtypes = [_F, _F, _F, C.c_int, C.c_int]
+        L.orc_divergence.argtypes = [_F, _F, _F, C.c_int, C.c_int]
+        L.orc_bicubic_at.argtypes = [_F, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_bicubic_at.restype = C.c_float
+        L.orc_bicubic_warp.argtypes = [_F, _F, _F, _F, C.c_int, C.c_int, C.c_int]
+        L.orc_rgb2gray.argtypes = [_F, C.c_int, C.c_int, _F]
+        L.orc_image_normalization_3.argtypes = [_F, _F, _F, _F, _F, _F, C.c_int]
+        L.orc_image_normalization_2.argtypes = [_F, _F, _F, _F, C.c_int]
+        L.orc_gaussian.argtypes = [_F, C.c_int, C.c_int, C.c_float]
+        L.orc_gaussian_taps.argtypes = [C.c_float, _F, C.c_int]
+        L.orc_preprocess_global.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int, _F, _F, _F]
+        L.orc_tvl1_global.argtypes = [_F, _F, _F, _F, _F, _F, _F, _F,
+                                      C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _I, _F]
+        L.orc_tvl1_global.restype = C.c_long
+        L.orc_tvl1_iteration.argtypes = [_F] * 12 + [C.c_float] * 3 + [C.c_int] * 2
+        L.orc_tvl1_iteration.restype = C.c_float
+        L.orc_tvl1_warp_constants.argtypes = [_F] * 10 + [C.c_int] * 2
+        L.orc_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The reference's own primitives (None when oracle/_ref was not built / did not travel)."""
+    global _ref
+    if _ref is None:
+        so = os.path.join(_HERE, "_ref", "libfaldoi_ref.so")
+        if not os.path.exists(so):
+            return None
+        R = C.CDLL(so)
+        R.ref_centered_gradient.argtypes = [_F, _F, _F, C.c_int, C.c_int]
+        R.ref_forward_gradient.argtypes = [_F, _F, _F, C.c_int, C.c_int]
+        R.ref_divergence.argtypes = [_F, _F, _F, C.c_int, C.c_int]
+        R.ref_gaussian.argtypes = [_F, C.c_int, C.c_int, C.c_float]
+        R.ref_image_normalization.argtypes = [_F, _F, _F, _F, C.c_int]
+        R.ref_image_normalization_3.argtypes = [_F, _F, _F, _F, _F, _F, C.c_int]
+        R.ref_bicubic_at.argtypes = [_F, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
+        R.ref_bicubic_at.restype = C.c_float
+        R.ref_bicubic_warp.argtypes = [_F, _F, _F, _F, C.c_int, C.c_int, C.c_int]
+        _ref = R
+    return _ref
+
+
+# ---------------------------------------------------------------- convenience wrappers
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def centered_gradient(img):
+    h, w = img.shape
+    dx, dy = np.empty_like(img), np.empty_like(img)
+    lib().orc_centered_gradient(img, dx, dy, w, h)
+    return dx, dy
+
+
+def preprocess_global(i0, i1, im1=None):
+    """i0,i1[,im1]: (pd,h,w) float32 planar 0..255.  Returns (i0n, i1n) as the solver sees them."""
+    i0, i1 = f32(i0), f32(i1)
+    im1 = i1 if im1 is None else f32(im1)
+    pd, h, w = i0.shape
+    o0, o1, o2 = (np.empty((h, w), np.float32) for _ in range(3))
+    lib().orc_preprocess_global(i0, i1, im1, w, h, pd, o0, o1, o2)
+    return o0, o1
+
+
+def tvl1_global(i0n, i1n, u0, lam=40.0, theta=0.3, tau=0.125, tol=0.01, warps=5,
+                max_inner=400, tol_stop=True, xi=None):
+    """Runs the oracle solver.  u0: (2,h,w).  Returns (u (2,h,w), iters[warps], err[warps], xi)."""
+    h, w = i0n.shape
+    u = f32(u0).copy()
+    xi = np.zeros((4, h, w), np.float32) if xi is None else f32(xi).copy()
+    iters = np.zeros(warps, np.int32)
+    errs = np.zeros(warps, np.float32)
+    lib().orc_tvl1_global(f32(i0n), f32(i1n), u[0], u[1], xi[0], xi[1], xi[2], xi[3],
+                          lam, theta, tau, tol, w, h, warps, max_inner, int(bool(tol_stop)),
+                          iters, errs)
+    return u, iters, errs, xi

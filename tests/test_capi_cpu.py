@@ -1,0 +1,70 @@
+"""CPU suite, part 2: the C-ABI library builds for gfx950, loads, and exports every symbol
+include/faldoi_hip.h declares.  No compute calls here (there is no GPU in CI), except to check
+that they fail loudly -- the product has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import faldoi_ipol_amd as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    L = F.capi.lib()
+    header = open(os.path.join(ROOT, "include", "faldoi_hip.h")).read()
+    declared = set(re.findall(r"\b(faldoi_[a-z0-9_]+)\s*\(", header))
+    declared -= {"faldoi_ctx", "faldoi_tvl1_batch"}
+    assert declared == set(F.capi.EXPORTS)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert L.faldoi_abi_version() == 1
+
+
+def test_default_params_are_the_reference_constants():
+    p = F.default_params()
+    # src/parameters.h:20-22,31,43,51
+    assert (p.lambda_, p.warps, p.max_inner, p.tol_stop) == (40.0, 5, 400, 1)
+    assert p.theta == np.float32(0.3) and p.tau == np.float32(0.125) and p.tol == np.float32(0.01)
+
+
+def _gpu_present():
+    n = ctypes.c_int(0)
+    return F.capi.lib().faldoi_device_count(ctypes.byref(n)) == 0 and n.value > 0
+
+
+def test_no_device_is_a_loud_error_not_a_fallback():
+    if _gpu_present():
+        pytest.skip("a GPU is present")
+    with pytest.raises(F.FaldoiError) as e:
+        F.Context(0)
+    assert e.value.code == F.capi.ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "faldoi-ipol_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text.lower().replace("oracle-verified", ""), fn
+
+
+def test_flo_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal((2, 5, 7)).astype(np.float32)
+    f[0, 0, 0] = np.nan                                     # sparse flows use NaN for "no seed"
+    p = tmp_path / "a.flo"
+    F.flo.write_flo(str(p), f)
+    raw = p.read_bytes()
+    assert raw[:4] == b"PIEH" and len(raw) == 12 + 8 * 35
+    g = F.flo.read_flo(str(p))
+    assert np.array_equal(f.view(np.uint32), g.view(np.uint32))
+    # interleaved layout: first pixel's (u, v)
+    assert np.frombuffer(raw, "<f4", 2, 12)[1] == f[1, 0, 0]
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.flo").write_bytes(b"PIEHxx")
+        F.flo.read_flo(str(tmp_path / "bad.flo"))
