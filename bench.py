@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the TV-L1 global minimisation hot path on MI355X.
+
+A "step" is ONE full solve of BASELINE.json configs[1]: a 1024x436 pair, 300 warps x 10 inner
+primal-dual iterations, tolerance stop off, fp32 -- i.e. 3000 inner iterations over 446 464 px.
+Inputs are resident in HBM before the timed region starts.  With --gpus N every rank solves its
+own pair (weak scaling; pairs are independent so there is no data-path collective).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md section 6 for how `roofline` is computed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 1024, 436
+WARPS, INNER = 300, 10
+BYTES_PER_PX_ITER = 76        # 19 fp32 planes touched once per inner iteration
+BYTES_PER_PX_WARP = 44        # per outer warp (bicubic gathers + constants)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs-per-gpu", type=int, default=1)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import faldoi_ipol_amd as F
+    from util import synthetic_pair
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    npairs = args.pairs_per_gpu
+    ctx = F.Context(local_rank)
+    batch = F.Tvl1Batch(ctx, npairs, W, H)
+    pairs = []
+    for i in range(npairs):
+        i0n, i1n, gt = synthetic_pair(W, H, seed=1234 + rank * npairs + i, amp=4.0)
+        u0 = np.zeros_like(gt)
+        batch.upload(i, i0n, i1n, u0)
+        pairs.append((i0n, i1n, u0))
+    prm = dict(warps=WARPS, max_inner=INNER, tol_stop=0, chunk=args.chunk)
+
+    def step():
+        return batch.solve(**prm)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    dev_ms, launches = 0.0, 0
+    for _ in range(args.steps):
+        iters, errs, ms, nl = step()          # returns after the solve's stop event has completed
+        dev_ms += ms
+        launches += nl
+    fence()
+    dt = time.perf_counter() - t0
+
+    px_iters_local = float(args.steps) * npairs * W * H * WARPS * INNER
+    dt_max, px_iters = F.shard.reduce_timing(dt, px_iters_local, dist if world > 1 else None, dev)
+
+    out = None
+    if rank == 0:
+        value = px_iters / dt_max / 1e6
+        launch_ms = dev_ms / max(launches, 1)
+        iters_per_launch = WARPS * INNER * args.steps / max(launches / 1, 1) if launches else 0
+        bytes_per_launch = npairs * W * H * (BYTES_PER_PX_ITER * (WARPS * INNER * args.steps / launches)
+                                             + BYTES_PER_PX_WARP * (WARPS * args.steps / launches))
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mpixels*warp-iters/sec on TV-L1 global_faldoi, Sintel 1024x436; EPE vs CPU ref",
+            "value": round(value, 1), "unit": "Mpx*iter/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "TV-L1 global minimisation, %d pair(s)/GPU of %dx%d, %d warps x %d inner "
+                                   "iterations, tolerance stop off (BASELINE configs[1])"
+                                   % (npairs, W, H, WARPS, INNER),
+                       "pairs_per_gpu": npairs, "parallelism": "pairs-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "tvl1_chunk_kernel",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launch_us": round(launch_ms * 1e3, 2),
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                         "inner_iters_per_launch": round(iters_per_launch, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O            # checker + timed CPU baseline only
+            i0n, i1n, u0 = pairs[0]
+            O.lib()
+            t1 = time.perf_counter()
+            ou, oit, _, _ = O.tvl1_global(i0n, i1n, u0, warps=WARPS, max_inner=INNER, tol_stop=False)
+            cpu_s = time.perf_counter() - t1
+            gu = batch.download(0)
+            epe = float(F.flo.epe(gu, ou).mean())
+            out["cpu_baseline"] = {"value": round(W * H * WARPS * INNER / cpu_s / 1e6, 1), "unit": "Mpx*iter/s",
+                                   "cores": int(O.lib().orc_num_threads()), "kind": "port",
+                                   "sample": "the full step once (1 pair, %d warps x %d iterations, %.1f s)"
+                                             % (WARPS, INNER, cpu_s)}
+            out["epe_vs_cpu"] = {"mean_epe_px": epe, "bit_identical": bool(
+                np.array_equal(gu.view(np.uint32), ou.view(np.uint32))), "gate": 1e-4}
+        print(json.dumps(out), flush=True)
+    batch.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

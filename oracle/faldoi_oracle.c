@@ -19,6 +19,15 @@
 #include <omp.h>
 #endif
 
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -73,6 +73,7 @@ void orc_tvl1_warp_constants(const float *I0, const float *I1, const float *I1x,
                              float *I1wx, float *I1wy, float *grad, float *rho_c, int nx, int ny);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

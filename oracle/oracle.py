@@ -29,12 +29,33 @@ _lib = None
 _ref = None
 
 
+def cpu_share():
+    """Host threads this job may use: the affinity mask, capped at the GPU box's 16-per-GPU share."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(16, avail))
+
+
+def _cap_threads():
+    """The GPU box exposes many more hardware threads than the CPU share a job may use (16 per
+    GPU); an OpenMP team sized by the former spends its time spinning.  Cap before libgomp loads."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, avail))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
 def lib():
     global _lib
     if _lib is None:
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
+        _cap_threads()
         L = C.CDLL(so)
         L.orc_centered_gradient.argtypes = [_F, _F, _F, C.c_int, C.c_int]
         L.orc_forward_gradient.argtypes = [_F, _F, _F, C.c_int, C.c_int]
@@ -56,6 +77,8 @@ def lib():
         L.orc_tvl1_iteration.restype = C.c_float
         L.orc_tvl1_warp_constants.argtypes = [_F] * 10 + [C.c_int] * 2
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads(cpu_share())      # libgomp may already be loaded (torch) with its own default
         _lib = L
     return _lib
 
