@@ -22,7 +22,7 @@ EXPORTS = [
     "faldoi_tvl1_batch_create", "faldoi_tvl1_batch_destroy", "faldoi_tvl1_batch_upload",
     "faldoi_tvl1_batch_reset", "faldoi_tvl1_batch_solve", "faldoi_tvl1_batch_download",
     "faldoi_tvl1_batch_last_timing", "faldoi_centered_gradient", "faldoi_forward_gradient",
-    "faldoi_divergence", "faldoi_bicubic_warp",
+    "faldoi_divergence", "faldoi_bicubic_warp", "faldoi_selftest_division",
 ]
 
 
@@ -87,6 +87,7 @@ def lib():
     L.faldoi_forward_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_divergence.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_bicubic_warp.argtypes = [vp, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int]
+    L.faldoi_selftest_division.argtypes = [vp, C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
 
@@ -165,6 +166,13 @@ class Context:
         o = np.empty_like(img)
         _check(lib().faldoi_bicubic_warp(self._h, img, u, v, o, w, h, int(bool(border_out))))
         return o
+
+    def selftest_division(self, count=1 << 28, seed=12345):
+        bad = C.c_ulonglong(0)
+        _check(lib().faldoi_selftest_division(self._h, int(seed), int(count), C.byref(bad)))
+        if bad.value:
+            print(lib().faldoi_last_error().decode())
+        return bad.value
 
     # ---- one-call solver (mirror of tvl2OF) ----
     def tvl1_global(self, i0n, i1n, u0, xi=None, **params):

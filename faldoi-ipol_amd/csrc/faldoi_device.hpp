@@ -20,6 +20,57 @@ namespace faldoi {
 __device__ __forceinline__ float grad_zero_bound() { return __uint_as_float(0x322bcc78u); }
 
 // ---------------------------------------------------------------------------------------------
+// Correctly rounded fp32 quotients through fp64 (gfx950: an IEEE fp32 divide costs ~40 SIMD
+// cycles, cvt+mul+2 fma+cvt in fp64 ~21, and one reciprocal serves several numerators).
+//
+//   rd  ~ 1/d in fp64, relative error <= 2^-27 suffices (recip_f64: v_rcp_f64 + one Newton step)
+//   q0  = a * rd                       (fp64)
+//   rem = a - d*q0  by one fma         (fp64, one rounding of an almost-cancelled sum)
+//   q1  = q0 + rem*rd  by one fma      error <= 2^-52 relative (Markstein correction)
+//   result = (float) q1                RN to fp32
+//
+// Why the last rounding gives RN(a/d): for fp32 a, d the exact quotient is never closer than
+// 2^-49 (relative) to a midpoint of two fp32 values unless it IS exactly representable in fp64
+// (ties only exist for subnormal fp32 results); in the first case an fp64 value within 2^-52
+// rounds the same way, in the second the correction step returns that fp64 value exactly and
+// the hardware conversion breaks the tie to even like the IEEE divide.  Signed zeros, subnormal
+// operands and subnormal results follow IEEE semantics because every step is an IEEE fp64
+// operation; NaN operands give NaN.  Domain: finite a, finite d > 0 (call sites: d = max(1,|xi|)
+// and d = theta > 0); an infinite numerator yields NaN instead of infinity -- only reachable
+// after the iteration has already overflowed.  Checked against the hardware IEEE divide on the
+// GPU over random bit patterns and edge cases by faldoi_selftest_division (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double recip_f64(float d)
+{
+    const double dd = (double)d;
+    const double r0 = __builtin_amdgcn_rcp(dd);                // v_rcp_f64: full fp32 range, >= 2^-20
+    const double e = __builtin_fma(-dd, r0, 1.0);
+    return __builtin_fma(e, r0, r0);                           // >= 2^-40
+}
+__device__ __forceinline__ float div_by(float a, float d, double rd)
+{
+    const double ad = (double)a, dd = (double)d;
+    const double q0 = ad * rd;
+    // negated residual times negated reciprocal: the same value as fma(a - d*q0, rd, q0), but an
+    // exactly cancelled residual (+0) then contributes -0, so a = -0 keeps its sign (d, rd > 0)
+    const double nrem = __builtin_fma(dd, q0, -ad);
+    return (float)__builtin_fma(nrem, -rd, q0);
+}
+
+// Neighbouring lanes of the wavefront (tile column x-1 / x+1) through the DPP crossbar.
+// Lanes without a source (0 / 63) keep their own value; the callers never use it (halo).
+__device__ __forceinline__ float lane_right(float v)     // value held by lane+1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_left(float v)      // value held by lane-1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stencil classes of a pixel (its position relative to the image frame).
 // ---------------------------------------------------------------------------------------------
 struct PixClass {
@@ -183,21 +234,23 @@ __device__ __forceinline__ void dual_step(float &xi11, float &xi12, float &xi21,
     const float g22 = xi22 * xi22;
     float n = sqrtf(g11 + g12 + g21 + g22);
     n = (1.0f > n) ? 1.0f : n;
-    xi11 = (xi11 + tau * u1x) / n;
-    xi12 = (xi12 + tau * u1y) / n;
-    xi21 = (xi21 + tau * u2x) / n;
-    xi22 = (xi22 + tau * u2y) / n;
+    const double rn = recip_f64(n);                 // one reciprocal, four exact quotients
+    xi11 = div_by(xi11 + tau * u1x, n, rn);
+    xi12 = div_by(xi12 + tau * u1y, n, rn);
+    xi21 = div_by(xi21 + tau * u2x, n, rn);
+    xi22 = div_by(xi22 + tau * u2y, n, rn);
 }
 
 // :307-342 ofTVl2_getP for one pixel, followed by the over-relaxation of :780-783.
 // Returns |du|^2 (u_N).
+// rtheta = fp64 reciprocal of theta (host: 1.0 / (double)theta), see div_by.
 __device__ __forceinline__ float primal_step(float &u1, float &u2, float &ub1, float &ub2,
                                              float v1, float v2, float div1, float div2,
-                                             float theta, float tau)
+                                             float theta, double rtheta, float tau)
 {
     const float u1k = u1, u2k = u2;
-    const float n1 = u1k - tau * (-div1 + (u1k - v1) / theta);
-    const float n2 = u2k - tau * (-div2 + (u2k - v2) / theta);
+    const float n1 = u1k - tau * (-div1 + div_by(u1k - v1, theta, rtheta));
+    const float n2 = u2k - tau * (-div2 + div_by(u2k - v2, theta, rtheta));
     const float e = (n1 - u1k) * (n1 - u1k) + (n2 - u2k) * (n2 - u2k);
     u1 = n1;
     u2 = n2;

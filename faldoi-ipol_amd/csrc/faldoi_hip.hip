@@ -172,21 +172,21 @@ static TileCfg pick_tile()
 template <int R, int NW>
 static hipError_t launch_chunk_t(dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int ntx, int nty,
                                  int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st, int cur,
-                                 int first, int iters, int slot)
+                                 int iters, int slot)
 {
     hipLaunchKernelGGL((tvl1_chunk_kernel<R, NW>), grid, dim3(64 * NW), 0, s, base, pe, nx, ny, ntx, nty, npairs, halo,
-                       prm, ctl, err, st, cur, first, iters, slot);
+                       prm, ctl, err, st, cur, iters, slot);
     return hipGetLastError();
 }
 
 static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int ntx,
                                int nty, int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st,
-                               int cur, int first, int iters, int slot)
+                               int cur, int iters, int slot)
 {
 #define FALDOI_CASE(r, w)                                                                                             \
     if (tc.R == r && tc.NW == w)                                                                                      \
-        return launch_chunk_t<r, w>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, first, \
-                                    iters, slot);
+        return launch_chunk_t<r, w>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, iters, \
+                                    slot);
     FALDOI_CASE(4, 16)
     FALDOI_CASE(8, 8)
     FALDOI_CASE(4, 8)
@@ -321,6 +321,7 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
     const bool dynamic = prm->tol_stop != 0;
 
     TvConst k;
+    k.rtheta = 1.0 / (double)prm->theta;
     k.l_t = prm->lambda * prm->theta;          // src/global_faldoi.cpp:577
     k.theta = prm->theta;
     k.tau = prm->tau;
@@ -350,6 +351,7 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
     }
 
     const int npix = b->nx * b->ny;
+    const dim3 wgrid(((npix + 255) / 256) * b->npairs);
     int launches = 0;
     HIP_TRY(hipEventRecord(c->ev0, s));
     HIP_TRY(hipMemsetAsync(b->d_done, 0, sizeof(int), s));
@@ -372,8 +374,13 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
             int n = 0;
             while (n < prm->max_inner) {
                 const int it = (prm->max_inner - n) < chunk ? (prm->max_inner - n) : chunk;
+                if (n == 0) {
+                    hipLaunchKernelGGL(tvl1_warp_kernel, wgrid, dim3(256), 0, s, b->slabs, b->plane_elems, b->nx, b->ny,
+                                       b->npairs, b->ctl, 1, cur);
+                    HIP_TRY(hipGetLastError());
+                }
                 HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
-                                     b->ctl, b->err_part, 1, cur, n == 0, it, w));
+                                     b->ctl, b->err_part, 1, cur, it, w));
                 ++launches;
                 cur ^= 1;
                 n += it;
@@ -390,8 +397,11 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
         const long max_launches = 2L * warps * ((prm->max_inner + chunk - 1) / chunk + 1) + group;
         for (;;) {
             for (int g = 0; g < group; ++g) {
+                hipLaunchKernelGGL(tvl1_warp_kernel, wgrid, dim3(256), 0, s, b->slabs, b->plane_elems, b->nx, b->ny,
+                                   b->npairs, b->ctl, 0, 0);
+                HIP_TRY(hipGetLastError());
                 HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
-                                     b->ctl, b->err_part, 0, 0, 0, 0, 0));
+                                     b->ctl, b->err_part, 0, 0, 0, 0));
                 hipLaunchKernelGGL(tvl1_ctl_kernel, dim3(b->npairs), dim3(256), 0, s, b->ctl, b->err_part, ntiles, k,
                                    b->d_iters, b->d_err, b->d_done);
                 HIP_TRY(hipGetLastError());
@@ -486,6 +496,45 @@ extern "C" int faldoi_tvl1_global(faldoi_ctx *ctx, const float *I0, const float 
     if (!rc) rc = faldoi_tvl1_batch_download(b, 0, u, xi);
     faldoi_tvl1_batch_destroy(b);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------ self-test
+extern "C" int faldoi_selftest_division(faldoi_ctx *ctx, unsigned seed, unsigned long long count,
+                                        unsigned long long *mismatches)
+{
+    if (!ctx || !mismatches) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    float *dump = nullptr;
+    const int dump_cap = getenv("FALDOI_SELFTEST_DUMP") ? 64 : 0;
+    if (dump_cap) HIP_TRY(hipMalloc((void **)&dump, sizeof(float) * 4 * dump_cap));
+    HIP_TRY(hipMalloc((void **)&d, sizeof h));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof h, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(selftest_division_kernel, dim3(2048), dim3(256), 0, ctx->stream, seed, count, d, dump,
+                           dump_cap);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && dump_cap) {
+        std::vector<float> hd(4 * dump_cap, 0.f);
+        e = hipMemcpy(hd.data(), dump, sizeof(float) * hd.size(), hipMemcpyDeviceToHost);
+        for (int i = 0; i < dump_cap && e == hipSuccess; ++i) {
+            unsigned b[4];
+            memcpy(b, &hd[4 * i], 16);
+            if (b[0] | b[1]) fprintf(stderr, "selftest offender a=%08x d=%08x ieee=%08x fp64=%08x\n", b[0], b[1], b[2], b[3]);
+        }
+        (void)hipFree(dump);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(FALDOI_ERR_HIP, "selftest failed: %s", hipGetErrorString(e));
+    *mismatches = h[0];
+    if (h[0])   // breakdown for the error text: dual-site, subnormal-result, huge-divisor cases
+        fail(FALDOI_OK, "division selftest: %llu mismatches (dual site %llu, subnormal result %llu, divisor>1e30 %llu)",
+             h[0], h[1], h[2], h[3]);
+    return FALDOI_OK;
 }
 
 // ------------------------------------------------------------------------------------------ primitives

@@ -1,7 +1,8 @@
 // tvl1_kernels.hpp -- HIP kernels of the TV-L1 global minimisation (gfx950 / MI355X).
 //
 // Design: the reference runs seven full-image passes per inner iteration
-// (src/global_faldoi.cpp:690-783, 208 B/px/iteration of traffic).  Here ONE launch advances a
+// (src/global_faldoi.cpp:690-783, 208 B/px/iteration of traffic).  Here one pointwise launch per
+// outer warp builds the warp constants, and ONE launch advances a
 // tile by up to FALDOI_MAX_CHUNK inner iterations with the whole per-pixel state held in
 // registers (temporal blocking): a workgroup loads its tile plus a halo as wide as the number
 // of iterations, iterates without touching HBM, and writes back only the tile interior, whose
@@ -34,6 +35,7 @@ enum Plane {
 };
 
 struct TvConst {
+    double rtheta;                 // 1 / (double)theta, for the exact fp64-assisted quotient
     float l_t, theta, tau, tol2;
     int max_inner, tol_stop, warps, chunk;
 };
@@ -117,6 +119,70 @@ __global__ void bicubic_warp_kernel(const float *__restrict__ in, const float *_
     }
 }
 
+// Self-test of the fp64-assisted quotient (faldoi_device.hpp: recip_f64/div_by) against the
+// hardware IEEE fp32 divide.  Sample i draws a numerator from a counter-based hash over ALL finite
+// bit patterns (every exponent incl. subnormals, both signs; every 16th sample is a special value)
+// and divides it (a) by max(1,|x|) for a hashed x, the dual step's divisor, and (b) by a hashed
+// theta in (2^-20, 4), the primal step's divisor.  Counts bitwise mismatches.
+__device__ __forceinline__ unsigned mix32(unsigned x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__global__ void selftest_division_kernel(unsigned seed, unsigned long long count, unsigned long long *mismatch,
+                                         float *dump, int dump_cap)
+{
+    unsigned long long bad = 0, bad_dual = 0, bad_sub = 0, bad_big = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned h0 = mix32((unsigned)i ^ seed), h1 = mix32(h0 + 0x9e3779b9u + (unsigned)(i >> 32));
+        const unsigned h2 = mix32(h1 ^ 0x85ebca6bu);
+        unsigned ab = h0;
+        if ((i & 15) == 0) {                                  // specials: zeros, subnormals, tie makers
+            const unsigned sel = (h1 >> 8) & 7;
+            ab = sel == 0 ? 0u : sel == 1 ? 0x80000000u : sel == 2 ? (h0 & 0x807fffffu)       // +-subnormal
+               : sel == 3 ? ((h0 & 0x80000007u) | 0x00000001u)                                 // tiny subnormal
+               : sel == 4 ? ((h0 & 0x80ffffffu) | 0x00800000u)                                 // smallest normals
+               : sel == 5 ? ((h0 & 0x807fffffu) | 0x7f000000u)                                 // huge
+               : sel == 6 ? (h0 & 0xff800000u) : h0;                                           // powers of two
+        }
+        if ((ab & 0x7f800000u) == 0x7f800000u) ab &= 0xbfffffffu;     // keep it finite
+        const float a = __uint_as_float(ab);
+        // (a) divisor of the dual step
+        unsigned xb = h1;
+        if ((xb & 0x7f800000u) == 0x7f800000u) xb &= 0xbfffffffu;
+        if ((i & 3) == 1) xb = (xb & 0x007fffffu) | 0x3f800000u | ((h2 & 3u) << 23);   // |x| in [1,16): the common case
+        float n = fabsf(__uint_as_float(xb));
+        n = (1.0f > n) ? 1.0f : n;
+        const float q_ref = a / n;
+        const float q_new = div_by(a, n, recip_f64(n));
+        const bool m1 = (__float_as_uint(q_ref) != __float_as_uint(q_new));
+        bad += m1;
+        bad_dual += m1;
+        bad_sub += m1 && (fabsf(q_ref) < 1.17549435e-38f);
+        bad_big += m1 && (n > 1e30f);
+        if (m1 && dump) {                                     // first few offenders, for diagnosis
+            const unsigned long long slot = atomicAdd(mismatch + 4, 1ull);
+            if (slot < (unsigned long long)dump_cap) {
+                dump[slot * 4 + 0] = a; dump[slot * 4 + 1] = n; dump[slot * 4 + 2] = q_ref; dump[slot * 4 + 3] = q_new;
+            }
+        }
+        // (b) divisor of the primal step
+        const float theta = __uint_as_float(0x35800000u + (h2 % 0x0b000000u));          // [2^-20, 4)
+        const float t_ref = a / theta;
+        const float t_new = div_by(a, theta, 1.0 / (double)theta);
+        const bool m2 = (__float_as_uint(t_ref) != __float_as_uint(t_new));
+        bad += m2;
+        bad_sub += m2 && (fabsf(t_ref) < 1.17549435e-38f);
+    }
+    if (bad) {
+        atomicAdd(mismatch, bad);
+        atomicAdd(mismatch + 1, bad_dual);
+        atomicAdd(mismatch + 2, bad_sub);
+        atomicAdd(mismatch + 3, bad_big);
+    }
+}
+
 // Copies the uploaded initial flow/duals into state buffer 0 and resets the control blocks.
 __global__ void reset_state_kernel(float *__restrict__ base, size_t plane_elems, int npix, int npairs,
                                    PairCtl *__restrict__ ctl, int first_iters)
@@ -143,7 +209,54 @@ __global__ void reset_state_kernel(float *__restrict__ base, size_t plane_elems,
 }
 
 // ---------------------------------------------------------------------------------------------
-// The fused kernel: [bicubic warp + per-warp constants] + `iters` primal-dual iterations.
+// Per-warp kernel: bicubic warp of I1, I1x, I1y by the current flow (border_out = true), the
+// per-warp constants rho_c / I1wx / I1wy, and ubar := u  (src/global_faldoi.cpp:635-660).
+// Pointwise in the flow, so it runs once per pixel (no halo).  In dynamic mode a pair takes part
+// only when its control block says the next chunk starts a warp.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tvl1_warp_kernel(float *__restrict__ base, size_t plane_elems, int nx, int ny,
+                                                        int npairs, const PairCtl *__restrict__ ctl, int static_mode,
+                                                        int s_cur)
+{
+    const int npix = nx * ny;
+    const int per_pair = (npix + 255) / 256;                   // blocks per pair
+    const int pair = blockIdx.x / per_pair;
+    if (pair >= npairs) return;
+    int cur = s_cur;
+    if (!static_mode) {
+        const PairCtl c = ctl[pair];
+        if (!c.first || c.iters <= 0) return;                   // uniform across the block
+        cur = c.cur;
+    }
+    const int p = (blockIdx.x - pair * per_pair) * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const int y = p / nx, x = p - y * nx;
+    float *slab = base + (size_t)pair * P_COUNT * plane_elems;
+    float *st = slab + (size_t)(cur ? P_STATE1 : P_STATE0) * plane_elems;
+    const float *I0 = slab + (size_t)P_I0 * plane_elems;
+    const float *I1 = slab + (size_t)P_I1 * plane_elems;
+    const float *I1x = slab + (size_t)P_I1X * plane_elems;
+    const float *I1y = slab + (size_t)P_I1Y * plane_elems;
+    const float u1 = st[0 * plane_elems + p];
+    const float u2 = st[1 * plane_elems + p];
+    const float uu = (float)x + u1;                             // src/bicubic_interpolation.c:259-260
+    const float vv = (float)y + u2;
+    const BicubicTaps tp = bicubic_taps(uu, vv, nx, ny);
+    float w0 = 0.0f, wx = 0.0f, wy = 0.0f;                      // border_out = true (:635-637)
+    if (!tp.clamped) {
+        w0 = bicubic_eval(I1, tp, nx);
+        wx = bicubic_eval(I1x, tp, nx);
+        wy = bicubic_eval(I1y, tp, nx);
+    }
+    slab[(size_t)P_RC * plane_elems + p] = rho_const(w0, wx, wy, u1, u2, I0[p]);
+    slab[(size_t)P_IWX * plane_elems + p] = wx;
+    slab[(size_t)P_IWY * plane_elems + p] = wy;
+    st[2 * plane_elems + p] = u1;                               // ubar = u (:659-660)
+    st[3 * plane_elems + p] = u2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused iteration kernel: `iters` primal-dual iterations on a register-resident tile.
 // ---------------------------------------------------------------------------------------------
 //
 // Grid: 8 * ceil(npairs*ntx*nty / 8) blocks of 64*NW threads.  Blocks are dealt to the 8 XCDs
@@ -161,7 +274,7 @@ template <int R, int NW>
 __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int ntx, int nty, int npairs,
     int halo, TvConst prm, const PairCtl *__restrict__ ctl, float *__restrict__ err_out,
-    int static_mode, int s_cur, int s_first, int s_iters, int err_slot)
+    int static_mode, int s_cur, int s_iters, int err_slot)
 {
     constexpr int TH = R * NW;
     __shared__ float s_ub1[NW][kTileW];
@@ -178,34 +291,35 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     const int tile = t - pair * ntiles;
     const int tyi = tile / ntx, txi = tile - tyi * ntx;
 
-    int cur, first, iters;
+    int cur, iters;
     if (static_mode) {
-        cur = s_cur; first = s_first; iters = s_iters;
+        cur = s_cur; iters = s_iters;
     } else {
         const PairCtl c = ctl[pair];
-        cur = c.cur; first = c.first; iters = c.iters;
+        cur = c.cur; iters = c.iters;
     }
     if (iters <= 0) return;                     // uniform across the block
 
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index, scalar
     const int Sx = kTileW - 2 * halo, Sy = TH - 2 * halo;
     const int gx = txi * Sx - halo + lane;
-    const int gy0 = tyi * Sy - halo + wv * R;
+    const int gy0 = tyi * Sy - halo + wv * R;   // scalar: every row test below is wave-uniform
     const bool col_in = gx >= 0 && gx < nx;
     const bool col_own = col_in && gx >= txi * Sx && gx < (txi + 1) * Sx;
+    // a wave whose rows all lie outside the image only takes part in the barriers
+    const bool wave_live = (gy0 + R > 0) && (gy0 < ny);
 
     float *slab = base + (size_t)pair * P_COUNT * plane_elems;
     const float *src = slab + (size_t)(cur ? P_STATE1 : P_STATE0) * plane_elems;
     float *dst = slab + (size_t)(cur ? P_STATE0 : P_STATE1) * plane_elems;
-    float *rcp = slab + (size_t)P_RC * plane_elems;
-    float *iwxp = slab + (size_t)P_IWX * plane_elems;
-    float *iwyp = slab + (size_t)P_IWY * plane_elems;
+    const float *rcp = slab + (size_t)P_RC * plane_elems;
+    const float *iwxp = slab + (size_t)P_IWX * plane_elems;
+    const float *iwyp = slab + (size_t)P_IWY * plane_elems;
 
-    float u1[R], u2[R], ub1[R], ub2[R], x11[R], x12[R], x21[R], x22[R], rc[R], ix[R], iy[R];
+    float u1[R], u2[R], ub1[R], ub2[R], x11[R], x12[R], x21[R], x22[R], rc[R], ix[R], iy[R], gr[R];
     bool in[R], own[R];
 
-    // ---- load (and, at the start of a warp, build the per-warp constants) ----
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int gy = gy0 + r;
@@ -214,53 +328,16 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
         const int p = in[r] ? gy * nx + gx : 0;
         u1[r] = in[r] ? src[0 * plane_elems + p] : 0.0f;
         u2[r] = in[r] ? src[1 * plane_elems + p] : 0.0f;
+        ub1[r] = in[r] ? src[2 * plane_elems + p] : 0.0f;
+        ub2[r] = in[r] ? src[3 * plane_elems + p] : 0.0f;
         x11[r] = in[r] ? src[4 * plane_elems + p] : 0.0f;
         x12[r] = in[r] ? src[5 * plane_elems + p] : 0.0f;
         x21[r] = in[r] ? src[6 * plane_elems + p] : 0.0f;
         x22[r] = in[r] ? src[7 * plane_elems + p] : 0.0f;
-    }
-    if (first) {
-        const float *I0 = slab + (size_t)P_I0 * plane_elems;
-        const float *I1 = slab + (size_t)P_I1 * plane_elems;
-        const float *I1x = slab + (size_t)P_I1X * plane_elems;
-        const float *I1y = slab + (size_t)P_I1Y * plane_elems;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            ub1[r] = u1[r];                                     // src/global_faldoi.cpp:659-660
-            ub2[r] = u2[r];
-            rc[r] = 0.0f; ix[r] = 0.0f; iy[r] = 0.0f;
-            if (in[r]) {
-                const int gy = gy0 + r;
-                const int p = gy * nx + gx;
-                const float uu = (float)gx + u1[r];             // src/bicubic_interpolation.c:259-260
-                const float vv = (float)gy + u2[r];
-                const BicubicTaps tp = bicubic_taps(uu, vv, nx, ny);
-                float w0 = 0.0f, wx = 0.0f, wy = 0.0f;          // border_out = true (:635-637)
-                if (!tp.clamped) {
-                    w0 = bicubic_eval(I1, tp, nx);
-                    wx = bicubic_eval(I1x, tp, nx);
-                    wy = bicubic_eval(I1y, tp, nx);
-                }
-                ix[r] = wx;
-                iy[r] = wy;
-                rc[r] = rho_const(w0, wx, wy, u1[r], u2[r], I0[p]);
-                if (own[r]) {                                   // later chunks of this warp reload them
-                    rcp[p] = rc[r];
-                    iwxp[p] = wx;
-                    iwyp[p] = wy;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int p = in[r] ? (gy0 + r) * nx + gx : 0;
-            ub1[r] = in[r] ? src[2 * plane_elems + p] : 0.0f;
-            ub2[r] = in[r] ? src[3 * plane_elems + p] : 0.0f;
-            rc[r] = in[r] ? rcp[p] : 0.0f;
-            ix[r] = in[r] ? iwxp[p] : 0.0f;
-            iy[r] = in[r] ? iwyp[p] : 0.0f;
-        }
+        rc[r] = in[r] ? rcp[p] : 0.0f;
+        ix[r] = in[r] ? iwxp[p] : 0.0f;
+        iy[r] = in[r] ? iwyp[p] : 0.0f;
+        gr[r] = grad_sq(ix[r], iy[r]);                          // src/global_faldoi.cpp:648-652
     }
 
     if (threadIdx.x < kMaxChunk) s_err[threadIdx.x] = 0u;
@@ -273,51 +350,56 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     for (int it = 0; it < iters; ++it) {
         __syncthreads();                                       // ubar row 0 of every wave visible
         // ---- dual step: forward gradient of ubar (:725-726) + ofTVl2_getD (:735) ----
-        const float dn1 = (wv < NW - 1) ? s_ub1[wv + 1][lane] : 0.0f;
-        const float dn2 = (wv < NW - 1) ? s_ub2[wv + 1][lane] : 0.0f;
+        if (wave_live) {
+            const float dn1 = (wv < NW - 1) ? s_ub1[wv < NW - 1 ? wv + 1 : wv][lane] : 0.0f;
+            const float dn2 = (wv < NW - 1) ? s_ub2[wv < NW - 1 ? wv + 1 : wv][lane] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int gy = gy0 + r;
-            const float r1 = __shfl_down(ub1[r], 1);
-            const float r2 = __shfl_down(ub2[r], 1);
-            const float d1 = (r < R - 1) ? ub1[r < R - 1 ? r + 1 : r] : dn1;
-            const float d2 = (r < R - 1) ? ub2[r < R - 1 ? r + 1 : r] : dn2;
-            const bool last_r = (gy == ny - 1);
-            dual_step(x11[r], x12[r], x21[r], x22[r],
-                      fwd_diff(r1, ub1[r], last_c), fwd_diff(d1, ub1[r], last_r),
-                      fwd_diff(r2, ub2[r], last_c), fwd_diff(d2, ub2[r], last_r), prm.tau);
+            for (int r = 0; r < R; ++r) {
+                const int gy = gy0 + r;
+                const float r1 = lane_right(ub1[r]);
+                const float r2 = lane_right(ub2[r]);
+                const float d1 = (r < R - 1) ? ub1[r < R - 1 ? r + 1 : r] : dn1;
+                const float d2 = (r < R - 1) ? ub2[r < R - 1 ? r + 1 : r] : dn2;
+                const bool last_r = (gy == ny - 1);
+                dual_step(x11[r], x12[r], x21[r], x22[r],
+                          fwd_diff(r1, ub1[r], last_c), fwd_diff(d1, ub1[r], last_r),
+                          fwd_diff(r2, ub2[r], last_c), fwd_diff(d2, ub2[r], last_r), prm.tau);
+            }
+            s_x12[wv][lane] = x12[R - 1];
+            s_x22[wv][lane] = x22[R - 1];
         }
-        s_x12[wv][lane] = x12[R - 1];
-        s_x22[wv][lane] = x22[R - 1];
         __syncthreads();                                       // new duals' last rows visible
         // ---- primal step: divergence (:745-746), TH (:690-718), getP (:770), relax (:780) ----
-        const float up12 = (wv > 0) ? s_x12[wv - 1][lane] : 0.0f;
-        const float up22 = (wv > 0) ? s_x22[wv - 1][lane] : 0.0f;
-        float emax = 0.0f;
+        if (wave_live) {
+            const float up12 = (wv > 0) ? s_x12[wv > 0 ? wv - 1 : 0][lane] : 0.0f;
+            const float up22 = (wv > 0) ? s_x22[wv > 0 ? wv - 1 : 0][lane] : 0.0f;
+            float emax = 0.0f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int gy = gy0 + r;
-            const PixClass pc{ first_c, last_c, gy == 0, gy == ny - 1 };
-            const float l11 = __shfl_up(x11[r], 1);
-            const float l21 = __shfl_up(x21[r], 1);
-            const float t12 = (r > 0) ? x12[r > 0 ? r - 1 : 0] : up12;
-            const float t22 = (r > 0) ? x22[r > 0 ? r - 1 : 0] : up22;
-            const float div1 = div_sample(x11[r], l11, x12[r], t12, pc);
-            const float div2 = div_sample(x21[r], l21, x22[r], t22, pc);
-            float v1, v2;
-            threshold_step(rc[r], ix[r], iy[r], grad_sq(ix[r], iy[r]), u1[r], u2[r], prm.l_t, v1, v2);
-            const float e = primal_step(u1[r], u2[r], ub1[r], ub2[r], v1, v2, div1, div2, prm.theta, prm.tau);
-            emax = (own[r] && e > emax) ? e : emax;
-        }
-        s_ub1[wv][lane] = ub1[0];
-        s_ub2[wv][lane] = ub2[0];
-        // max over the wavefront, then one LDS atomic per wave (order-independent => deterministic)
+            for (int r = 0; r < R; ++r) {
+                const int gy = gy0 + r;
+                const PixClass pc{ first_c, last_c, gy == 0, gy == ny - 1 };
+                const float l11 = lane_left(x11[r]);
+                const float l21 = lane_left(x21[r]);
+                const float t12 = (r > 0) ? x12[r > 0 ? r - 1 : 0] : up12;
+                const float t22 = (r > 0) ? x22[r > 0 ? r - 1 : 0] : up22;
+                const float div1 = div_sample(x11[r], l11, x12[r], t12, pc);
+                const float div2 = div_sample(x21[r], l21, x22[r], t22, pc);
+                float v1, v2;
+                threshold_step(rc[r], ix[r], iy[r], gr[r], u1[r], u2[r], prm.l_t, v1, v2);
+                const float e = primal_step(u1[r], u2[r], ub1[r], ub2[r], v1, v2, div1, div2, prm.theta,
+                                            prm.rtheta, prm.tau);
+                emax = (own[r] && e > emax) ? e : emax;
+            }
+            s_ub1[wv][lane] = ub1[0];
+            s_ub2[wv][lane] = ub2[0];
+            // max over the wavefront, then one LDS atomic per wave (order-independent => deterministic)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float other = __shfl_xor(emax, o);
-            emax = other > emax ? other : emax;
+            for (int o = 32; o > 0; o >>= 1) {
+                const float other = __shfl_xor(emax, o);
+                emax = other > emax ? other : emax;
+            }
+            if (lane == 0) atomicMax(&s_err[it], __float_as_uint(emax));
         }
-        if (lane == 0) atomicMax(&s_err[it], __float_as_uint(emax));
     }
 
     // ---- store the owned interior into the other state buffer ----

@@ -131,6 +131,13 @@ int faldoi_divergence(faldoi_ctx *ctx, const float *v1, const float *v2, float *
 int faldoi_bicubic_warp(faldoi_ctx *ctx, const float *in, const float *u, const float *v, float *out,
                         int nx, int ny, int border_out);
 
+/* ---------------------------------------------------------------- self-test
+ * The kernels replace the IEEE fp32 divide on two call sites by an fp64-assisted sequence that
+ * is proven to return the same bits (csrc/faldoi_device.hpp).  This entry point checks the claim
+ * on the device: `count` hashed samples over all finite bit patterns; *mismatches must be 0. */
+int faldoi_selftest_division(faldoi_ctx *ctx, unsigned seed, unsigned long long count,
+                             unsigned long long *mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,12 @@ def test_bicubic_warp_bit_exact_incl_out_of_range(ctx, oracle, border_out):
     assert bits_equal(got, want), mismatch_report(got, want)
 
 
+def test_fp64_assisted_quotient_equals_ieee_divide(ctx):
+    # 2^30 hashed samples x 2 call sites, all exponents incl. subnormals and tie makers
+    assert ctx.selftest_division(count=1 << 30, seed=1) == 0
+    assert ctx.selftest_division(count=1 << 26, seed=0xdeadbeef) == 0
+
+
 # ------------------------------------------------------------------ whole solver
 def _compare_solve(ctx, oracle, i0n, i1n, u0, xi0=None, **prm):
     ou, oit, oerr, oxi = oracle.tvl1_global(i0n, i1n, u0, xi=xi0,
