@@ -17,7 +17,10 @@ DEPS = SOURCES + [os.path.join(HERE, "csrc", f) for f in ("faldoi_device.hpp", "
 # -ffp-contract=off: parity with the reference CPU path needs un-fused multiply-adds.
 # fp32 divide / sqrt stay on hipcc's default correctly-rounded expansions; denormals are kept.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-fno-gpu-flush-denormals-to-zero"]
+               "-fno-gpu-flush-denormals-to-zero",
+               # the SLP vectoriser packs fp32 pairs into v_pk_* ops, which on gfx950 cost two plain ops
+               # plus the register moves that assemble the pairs (tools/ubench_valu.hip) -- a net loss here
+               "-fno-slp-vectorize"]
 
 
 def hipcc():

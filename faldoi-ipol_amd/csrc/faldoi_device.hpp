@@ -58,16 +58,34 @@ __device__ __forceinline__ float div_by(float a, float d, double rd)
 }
 
 // Neighbouring lanes of the wavefront (tile column x-1 / x+1) through the DPP crossbar.
-// Lanes without a source (0 / 63) keep their own value; the callers never use it (halo).
+// Lanes without a source (63 / 0) read 0 (bound_ctrl); the callers never use it (halo).  old = 0
+// with bound_ctrl lets the compiler fold the move into the consuming VOP2 (v_sub_f32_dpp).
 __device__ __forceinline__ float lane_right(float v)     // value held by lane+1
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                                0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v),
+                                                                0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_left(float v)      // value held by lane-1
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                                0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v),
+                                                                0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+
+// Correctly rounded square root for x in [1, +inf] (and NaN): v_sqrt_f32 is within 1 ulp, so the
+// result is one of {y-1ulp, y, y+1ulp}; the two fused residuals x - c*y pick it.  This is the
+// correction hipcc itself emits for sqrtf, without the input scaling / zero / subnormal handling
+// that a general argument needs (here x >= 1).  Checked exhaustively on the GPU against sqrtf for
+// every float in [1, FLT_MAX] by faldoi_selftest_division.
+__device__ __forceinline__ float sqrt_ge1(float x)
+{
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float yd = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    const float yu = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    const float rd = __builtin_fmaf(-yd, y, x);
+    const float ru = __builtin_fmaf(-yu, y, x);
+    float r = (rd <= 0.0f) ? yd : y;
+    r = (ru > 0.0f) ? yu : r;
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -232,13 +250,26 @@ __device__ __forceinline__ void dual_step(float &xi11, float &xi12, float &xi21,
     const float g12 = xi12 * xi12;
     const float g21 = xi21 * xi21;
     const float g22 = xi22 * xi22;
-    float n = sqrtf(g11 + g12 + g21 + g22);
-    n = (1.0f > n) ? 1.0f : n;
+    const float g = g11 + g12 + g21 + g22;
+    const float a11 = xi11 + tau * u1x;
+    const float a12 = xi12 + tau * u1y;
+    const float a21 = xi21 + tau * u2x;
+    const float a22 = xi22 + tau * u2y;
+    // g <= 1  =>  sqrt(g) <= 1 (correctly rounded)  =>  max(1, sqrt(g)) == 1  =>  a / 1 == a.
+    // When no lane of the wavefront has g > 1 the square root and the four quotients are skipped
+    // as a whole (wave-uniform branch); otherwise every lane takes the general path, which
+    // returns the same bits for the g <= 1 lanes.  (NaN g: both paths leave NaN duals.)
+    if (__builtin_amdgcn_ballot_w64(g > 1.0f) == 0ull) {
+        xi11 = a11; xi12 = a12; xi21 = a21; xi22 = a22;
+        return;
+    }
+    // max(1, sqrt(g)) == sqrt(max(1, g)): sqrt is monotone and sqrt(1) == 1 exactly
+    const float n = sqrt_ge1((g > 1.0f) ? g : 1.0f);
     const double rn = recip_f64(n);                 // one reciprocal, four exact quotients
-    xi11 = div_by(xi11 + tau * u1x, n, rn);
-    xi12 = div_by(xi12 + tau * u1y, n, rn);
-    xi21 = div_by(xi21 + tau * u2x, n, rn);
-    xi22 = div_by(xi22 + tau * u2y, n, rn);
+    xi11 = div_by(a11, n, rn);
+    xi12 = div_by(a12, n, rn);
+    xi21 = div_by(a21, n, rn);
+    xi22 = div_by(a22, n, rn);
 }
 
 // :307-342 ofTVl2_getP for one pixel, followed by the over-relaxation of :780-783.

@@ -161,8 +161,9 @@ static TileCfg pick_tile()
     if (const char *s = getenv("FALDOI_TILE")) {     // tuning aid: "R,NW"
         int r = 0, w = 0;
         if (sscanf(s, "%d,%d", &r, &w) == 2) {
-            if ((r == 4 && w == 16) || (r == 8 && w == 8) || (r == 4 && w == 8) || (r == 2 && w == 16) ||
-                (r == 6 && w == 8) || (r == 3 && w == 16))
+            if ((r == 4 && (w == 16 || w == 14 || w == 12 || w == 11 || w == 10 || w == 8)) ||
+                (r == 3 && (w == 16 || w == 14 || w == 12)) || (r == 8 && w == 8) || (r == 6 && w == 8) ||
+                (r == 2 && w == 16))
                 t = TileCfg{r, w};
         }
     }
@@ -188,11 +189,17 @@ static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base
         return launch_chunk_t<r, w>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, iters, \
                                     slot);
     FALDOI_CASE(4, 16)
-    FALDOI_CASE(8, 8)
+    FALDOI_CASE(4, 14)
+    FALDOI_CASE(4, 12)
+    FALDOI_CASE(4, 11)
+    FALDOI_CASE(4, 10)
     FALDOI_CASE(4, 8)
-    FALDOI_CASE(2, 16)
-    FALDOI_CASE(6, 8)
     FALDOI_CASE(3, 16)
+    FALDOI_CASE(3, 14)
+    FALDOI_CASE(3, 12)
+    FALDOI_CASE(8, 8)
+    FALDOI_CASE(6, 8)
+    FALDOI_CASE(2, 16)
 #undef FALDOI_CASE
     return hipErrorInvalidValue;
 }

@@ -175,6 +175,12 @@ __global__ void selftest_division_kernel(unsigned seed, unsigned long long count
         bad += m2;
         bad_sub += m2 && (fabsf(t_ref) < 1.17549435e-38f);
     }
+    // exhaustive: sqrt_ge1 against sqrtf for every float in [1, FLT_MAX] (and +inf)
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+         i <= 0x7f800000ull - 0x3f800000ull; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(0x3f800000u + (unsigned)i);
+        bad += (__float_as_uint(sqrt_ge1(x)) != __float_as_uint(__builtin_sqrtf(x)));
+    }
     if (bad) {
         atomicAdd(mismatch, bad);
         atomicAdd(mismatch + 1, bad_dual);
@@ -214,7 +220,7 @@ __global__ void reset_state_kernel(float *__restrict__ base, size_t plane_elems,
 // Pointwise in the flow, so it runs once per pixel (no halo).  In dynamic mode a pair takes part
 // only when its control block says the next chunk starts a warp.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tvl1_warp_kernel(float *__restrict__ base, size_t plane_elems, int nx, int ny,
+__global__ __launch_bounds__(256, 8) void tvl1_warp_kernel(float *__restrict__ base, size_t plane_elems, int nx, int ny,
                                                         int npairs, const PairCtl *__restrict__ ctl, int static_mode,
                                                         int s_cur)
 {
@@ -270,36 +276,18 @@ __global__ __launch_bounds__(256) void tvl1_warp_kernel(float *__restrict__ base
 //
 // err_out[(err_slot*ntiles_total + tile_global) * kMaxChunk + i] = max |du|^2 over the owned
 // pixels after iteration i of this launch (plain stores, reduced by tvl1_ctl_kernel).
-template <int R, int NW>
-__global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
-    float *__restrict__ base, size_t plane_elems, int nx, int ny, int ntx, int nty, int npairs,
-    int halo, TvConst prm, const PairCtl *__restrict__ ctl, float *__restrict__ err_out,
-    int static_mode, int s_cur, int s_iters, int err_slot)
+// BORDER = false is the specialisation for tiles whose 64 x TH footprint contains no pixel of
+// the image frame (first/last row or column): every stencil uses the interior formula, no
+// per-pixel class selects.  Chosen per workgroup (uniform branch) by the kernel below.
+template <int R, int NW, bool BORDER>
+__device__ __forceinline__ void tvl1_chunk_body(
+    float *__restrict__ base, size_t plane_elems, int nx, int ny, int npairs, int ntiles, int t,
+    int pair, int txi, int tyi, int halo, const TvConst &prm, float *__restrict__ err_out,
+    int cur, int iters, int err_slot,
+    float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW], float (*s_x22)[kTileW],
+    unsigned (*s_err)[kTileW])
 {
     constexpr int TH = R * NW;
-    __shared__ float s_ub1[NW][kTileW];
-    __shared__ float s_ub2[NW][kTileW];
-    __shared__ float s_x12[NW][kTileW];
-    __shared__ float s_x22[NW][kTileW];
-    __shared__ unsigned s_err[kMaxChunk];
-
-    const int per = gridDim.x >> 3;
-    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const int ntiles = ntx * nty;
-    if (t >= ntiles * npairs) return;
-    const int pair = t / ntiles;
-    const int tile = t - pair * ntiles;
-    const int tyi = tile / ntx, txi = tile - tyi * ntx;
-
-    int cur, iters;
-    if (static_mode) {
-        cur = s_cur; iters = s_iters;
-    } else {
-        const PairCtl c = ctl[pair];
-        cur = c.cur; iters = c.iters;
-    }
-    if (iters <= 0) return;                     // uniform across the block
-
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index, scalar
     const int Sx = kTileW - 2 * halo, Sy = TH - 2 * halo;
@@ -340,50 +328,63 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
         gr[r] = grad_sq(ix[r], iy[r]);                          // src/global_faldoi.cpp:648-652
     }
 
-    if (threadIdx.x < kMaxChunk) s_err[threadIdx.x] = 0u;
+    for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;
     s_ub1[wv][lane] = ub1[0];
     s_ub2[wv][lane] = ub2[0];
 
-    const bool last_c = (gx == nx - 1);
-    const bool first_c = (gx == 0);
+    const bool last_c = BORDER && (gx == nx - 1);
+    const bool first_c = BORDER && (gx == 0);
 
     for (int it = 0; it < iters; ++it) {
+        // Rows whose values can still reach the owned rows [halo, TH-halo) before the launch ends:
+        // after this iteration u is needed on tile rows [need_lo, need_hi), the new duals one row
+        // further up (the divergence reads xi12/xi22 of the row above).  Everything else is skipped
+        // (scalar tests: tile row = wv*R + r is wave-uniform).
+        const int reach = iters - 1 - it;
+        const int need_lo = halo - reach, need_hi = TH - halo + reach;
         __syncthreads();                                       // ubar row 0 of every wave visible
         // ---- dual step: forward gradient of ubar (:725-726) + ofTVl2_getD (:735) ----
-        if (wave_live) {
+        if (wave_live && wv * R + R > need_lo - 1 && wv * R < need_hi) {
             const float dn1 = (wv < NW - 1) ? s_ub1[wv < NW - 1 ? wv + 1 : wv][lane] : 0.0f;
             const float dn2 = (wv < NW - 1) ? s_ub2[wv < NW - 1 ? wv + 1 : wv][lane] : 0.0f;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int gy = gy0 + r;
                 const float r1 = lane_right(ub1[r]);
                 const float r2 = lane_right(ub2[r]);
                 const float d1 = (r < R - 1) ? ub1[r < R - 1 ? r + 1 : r] : dn1;
                 const float d2 = (r < R - 1) ? ub2[r < R - 1 ? r + 1 : r] : dn2;
-                const bool last_r = (gy == ny - 1);
-                dual_step(x11[r], x12[r], x21[r], x22[r],
-                          fwd_diff(r1, ub1[r], last_c), fwd_diff(d1, ub1[r], last_r),
-                          fwd_diff(r2, ub2[r], last_c), fwd_diff(d2, ub2[r], last_r), prm.tau);
+                const bool last_r = BORDER && (gy0 + r == ny - 1);
+                if (wv * R + r >= need_lo - 1 && wv * R + r < need_hi)
+                    dual_step(x11[r], x12[r], x21[r], x22[r],
+                              fwd_diff(r1, ub1[r], last_c), fwd_diff(d1, ub1[r], last_r),
+                              fwd_diff(r2, ub2[r], last_c), fwd_diff(d2, ub2[r], last_r), prm.tau);
             }
             s_x12[wv][lane] = x12[R - 1];
             s_x22[wv][lane] = x22[R - 1];
         }
         __syncthreads();                                       // new duals' last rows visible
         // ---- primal step: divergence (:745-746), TH (:690-718), getP (:770), relax (:780) ----
-        if (wave_live) {
+        if (wave_live && wv * R + R > need_lo && wv * R < need_hi) {
             const float up12 = (wv > 0) ? s_x12[wv > 0 ? wv - 1 : 0][lane] : 0.0f;
             const float up22 = (wv > 0) ? s_x22[wv > 0 ? wv - 1 : 0][lane] : 0.0f;
             float emax = 0.0f;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int gy = gy0 + r;
-                const PixClass pc{ first_c, last_c, gy == 0, gy == ny - 1 };
+                if (wv * R + r < need_lo || wv * R + r >= need_hi) continue;
                 const float l11 = lane_left(x11[r]);
                 const float l21 = lane_left(x21[r]);
                 const float t12 = (r > 0) ? x12[r > 0 ? r - 1 : 0] : up12;
                 const float t22 = (r > 0) ? x22[r > 0 ? r - 1 : 0] : up22;
-                const float div1 = div_sample(x11[r], l11, x12[r], t12, pc);
-                const float div2 = div_sample(x21[r], l21, x22[r], t22, pc);
+                float div1, div2;
+                if (BORDER) {
+                    const PixClass pc{ first_c, last_c, gy == 0, gy == ny - 1 };
+                    div1 = div_sample(x11[r], l11, x12[r], t12, pc);
+                    div2 = div_sample(x21[r], l21, x22[r], t22, pc);
+                } else {                                       // src/utils.cpp:250-256
+                    div1 = (x11[r] - l11) + (x12[r] - t12);
+                    div2 = (x21[r] - l21) + (x22[r] - t22);
+                }
                 float v1, v2;
                 threshold_step(rc[r], ix[r], iy[r], gr[r], u1[r], u2[r], prm.l_t, v1, v2);
                 const float e = primal_step(u1[r], u2[r], ub1[r], ub2[r], v1, v2, div1, div2, prm.theta,
@@ -392,13 +393,9 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
             }
             s_ub1[wv][lane] = ub1[0];
             s_ub2[wv][lane] = ub2[0];
-            // max over the wavefront, then one LDS atomic per wave (order-independent => deterministic)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float other = __shfl_xor(emax, o);
-                emax = other > emax ? other : emax;
-            }
-            if (lane == 0) atomicMax(&s_err[it], __float_as_uint(emax));
+            // per-lane running maximum of this iteration (values >= 0: uint order == float order;
+            // max is order-independent => deterministic); reduced across lanes once, at the end
+            atomicMax(&s_err[it][lane], __float_as_uint(emax));
         }
     }
 
@@ -418,11 +415,60 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
         }
     }
     __syncthreads();
-    if (threadIdx.x < kMaxChunk) {
-        const size_t slot = (size_t)err_slot * ntiles * npairs + t;
-        err_out[slot * kMaxChunk + threadIdx.x] =
-            (threadIdx.x < iters) ? __uint_as_float(s_err[threadIdx.x]) : 0.0f;
+    // wave i reduces iteration i's 64 per-lane maxima
+    for (int i = wv; i < kMaxChunk; i += NW) {
+        float m = (i < iters) ? __uint_as_float(s_err[i][lane]) : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(m, o);
+            m = other > m ? other : m;
+        }
+        if (lane == 0) {
+            const size_t slot = (size_t)err_slot * ntiles * npairs + t;
+            err_out[slot * kMaxChunk + i] = m;
+        }
     }
+}
+
+template <int R, int NW>
+__global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
+    float *__restrict__ base, size_t plane_elems, int nx, int ny, int ntx, int nty, int npairs,
+    int halo, TvConst prm, const PairCtl *__restrict__ ctl, float *__restrict__ err_out,
+    int static_mode, int s_cur, int s_iters, int err_slot)
+{
+    constexpr int TH = R * NW;
+    __shared__ float s_ub1[NW][kTileW];
+    __shared__ float s_ub2[NW][kTileW];
+    __shared__ float s_x12[NW][kTileW];
+    __shared__ float s_x22[NW][kTileW];
+    __shared__ unsigned s_err[kMaxChunk][kTileW];
+
+    const int per = gridDim.x >> 3;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int ntiles = ntx * nty;
+    if (t >= ntiles * npairs) return;
+    const int pair = t / ntiles;
+    const int tile = t - pair * ntiles;
+    const int tyi = tile / ntx, txi = tile - tyi * ntx;
+
+    int cur, iters;
+    if (static_mode) {
+        cur = s_cur; iters = s_iters;
+    } else {
+        const PairCtl c = ctl[pair];
+        cur = c.cur; iters = c.iters;
+    }
+    if (iters <= 0) return;                     // uniform across the block
+
+    // does the tile footprint [X0, X0+64) x [Y0, Y0+TH) touch the image frame?
+    const int X0 = txi * (kTileW - 2 * halo) - halo, Y0 = tyi * (TH - 2 * halo) - halo;
+    const bool border = X0 <= 0 || X0 + kTileW >= nx || Y0 <= 0 || Y0 + TH >= ny;
+    if (border)
+        tvl1_chunk_body<R, NW, true>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out,
+                                     cur, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err);
+    else
+        tvl1_chunk_body<R, NW, false>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out,
+                                      cur, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -22,12 +22,20 @@ def main():
     ap.add_argument("--pairs", type=int, default=1)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--size", default="1024x436")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "sintel"])
     a = ap.parse_args()
     w, h = map(int, a.size.split("x"))
     ctx = F.Context(0)
     b = F.Tvl1Batch(ctx, a.pairs, w, h)
     for i in range(a.pairs):
-        i0n, i1n, gt = synthetic_pair(w, h, seed=1234 + i, amp=4.0)
+        if a.data == "sintel":          # tuning tool only: preprocessing borrowed from the checker
+            from oracle import oracle as O
+            from util import sintel_pair
+            i0, i1 = sintel_pair()
+            i0n, i1n = O.preprocess_global(i0, i1)
+            gt = np.zeros((2, h, w), np.float32)
+        else:
+            i0n, i1n, gt = synthetic_pair(w, h, seed=1234 + i, amp=4.0)
         b.upload(i, i0n, i1n, np.zeros_like(gt))
     res = {}
     for rnd in range(a.rounds + 1):
