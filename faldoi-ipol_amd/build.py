@@ -11,8 +11,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libfaldoi_hip.so")
 SOURCES = [os.path.join(HERE, "csrc", "faldoi_hip.hip")]
-DEPS = SOURCES + [os.path.join(HERE, "csrc", f) for f in ("faldoi_device.hpp", "tvl1_kernels.hpp")] + [
+DEPS = SOURCES + [os.path.join(HERE, "csrc", f) for f in ("faldoi_device.hpp", "tvl1_kernels.hpp",
+                                                          "preprocess_kernels.hpp")] + [
     os.path.join(ROOT, "include", "faldoi_hip.h")]
+BIN = os.path.join(HERE, "bin")
+HOST = os.path.join(HERE, "host")
+HOST_COMMON = [os.path.join(HOST, "image_io.cpp")]
+HOST_PROGRAMS = {          # name -> (sources, needs libfaldoi_hip)
+    "global_faldoi": ([os.path.join(HOST, "global_faldoi.cpp")], True),
+    "sparse_flow": ([os.path.join(HOST, "sparse_flow.cpp")], False),
+    "faldoi_imginfo": ([os.path.join(HOST, "imginfo.cpp")], False),
+}
 
 # -ffp-contract=off: parity with the reference CPU path needs un-fused multiply-adds.
 # fp32 divide / sqrt stay on hipcc's default correctly-rounded expansions; denormals are kept.
@@ -48,5 +57,28 @@ def build(force=False, verbose=False):
     return SO
 
 
+def build_host(force=False, verbose=False):
+    """The reference's command-line surface (C++17, g++): global_faldoi over the C ABI, sparse_flow."""
+    os.makedirs(BIN, exist_ok=True)
+    cxx = shutil.which("g++") or "g++"
+    hdrs = [os.path.join(HOST, f) for f in ("image_io.hpp", "options.hpp")] + [os.path.join(ROOT, "include", "faldoi_hip.h")]
+    out = {}
+    for name, (srcs, needs_lib) in HOST_PROGRAMS.items():
+        exe = os.path.join(BIN, name)
+        out[name] = exe
+        deps = srcs + HOST_COMMON + hdrs + ([SO] if needs_lib else [])
+        if not force and os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
+            continue
+        cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, "-o", exe] + srcs + HOST_COMMON
+        if needs_lib:
+            cmd += ["-L" + HERE, "-lfaldoi_hip", "-Wl,-rpath,$ORIGIN/.."]
+        cmd += ["-lz"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

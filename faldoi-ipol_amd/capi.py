@@ -23,6 +23,7 @@ EXPORTS = [
     "faldoi_tvl1_batch_reset", "faldoi_tvl1_batch_solve", "faldoi_tvl1_batch_download",
     "faldoi_tvl1_batch_last_timing", "faldoi_centered_gradient", "faldoi_forward_gradient",
     "faldoi_divergence", "faldoi_bicubic_warp", "faldoi_selftest_division",
+    "faldoi_preprocess_global", "faldoi_tvl1_batch_upload_images",
 ]
 
 
@@ -87,6 +88,8 @@ def lib():
     L.faldoi_forward_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_divergence.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_bicubic_warp.argtypes = [vp, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int]
+    L.faldoi_preprocess_global.argtypes = [vp, _F, _F, vp, C.c_int, C.c_int, C.c_int, _F, _F]
+    L.faldoi_tvl1_batch_upload_images.argtypes = [vp, C.c_int, _F, _F, vp, C.c_int, _F, vp]
     L.faldoi_selftest_division.argtypes = [vp, C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
@@ -167,6 +170,15 @@ class Context:
         _check(lib().faldoi_bicubic_warp(self._h, img, u, v, o, w, h, int(bool(border_out))))
         return o
 
+    def preprocess_global(self, i0, i1, im1=None):
+        """(pd,h,w) planar images 0..255 -> (i0n, i1n) as the solver takes them (GPU)."""
+        i0, i1 = _f32(i0), _f32(i1)
+        im1 = None if im1 is None else _f32(im1)
+        pd, h, w = i0.shape
+        o0, o1 = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+        _check(lib().faldoi_preprocess_global(self._h, i0, i1, _ptr(im1), w, h, pd, o0, o1))
+        return o0, o1
+
     def selftest_division(self, count=1 << 28, seed=12345):
         bad = C.c_ulonglong(0)
         _check(lib().faldoi_selftest_division(self._h, int(seed), int(count), C.byref(bad)))
@@ -211,6 +223,13 @@ class Tvl1Batch:
     def upload(self, pair, i0n, i1n, u0, xi=None):
         xi = None if xi is None else _f32(xi)
         _check(lib().faldoi_tvl1_batch_upload(self._h, int(pair), _f32(i0n), _f32(i1n), _f32(u0), _ptr(xi)))
+
+    def upload_images(self, pair, i0, i1, u0, im1=None, xi=None):
+        i0, i1 = _f32(i0), _f32(i1)
+        im1 = None if im1 is None else _f32(im1)
+        xi = None if xi is None else _f32(xi)
+        _check(lib().faldoi_tvl1_batch_upload_images(self._h, int(pair), i0, i1, _ptr(im1), i0.shape[0],
+                                                     _f32(u0), _ptr(xi)))
 
     def solve(self, **params):
         p = default_params(**params)

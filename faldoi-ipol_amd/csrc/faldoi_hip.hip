@@ -5,9 +5,11 @@
 // entry point either launches HIP kernels or fails with a status code.
 #include "faldoi_hip.h"
 #include "tvl1_kernels.hpp"
+#include "preprocess_kernels.hpp"
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -149,6 +151,8 @@ extern "C" int faldoi_ctx_synchronize(faldoi_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FALDOI_OK;
 }
+
+static float *plane_ptr(faldoi_tvl1_batch *b, int pair, int plane);
 
 // ------------------------------------------------------------------------------------------ tiling
 struct TileCfg {
@@ -503,6 +507,138 @@ extern "C" int faldoi_tvl1_global(faldoi_ctx *ctx, const float *I0, const float 
     if (!rc) rc = faldoi_tvl1_batch_download(b, 0, u, xi);
     faldoi_tvl1_batch_destroy(b);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------ preprocessing
+// Normalised Gaussian half-kernel exactly as src/utils.cpp:529-552 builds it in its C++ translation
+// unit: the exponent argument is fp32 and exp() resolves to the fp32 overload, the prefactor and
+// the product are fp64, the normalisation accumulates in fp32.
+static int gaussian_taps(float sigma, GaussTaps *t)
+{
+    const float den = 2 * sigma * sigma;
+    const int size = (int)(5 * sigma) + 1;
+    if (!(sigma > 0) || size > kMaxGaussTaps) return -1;
+    for (int i = 0; i < size; i++) {
+        const float arg = -i * i / den;
+        t->B[i] = (float)(1 / (sigma * std::sqrt(2.0 * 3.1415926)) * (double)expf(arg));
+    }
+    float norm = 0;
+    for (int i = 0; i < size; i++) norm += t->B[i];
+    norm *= 2;
+    norm -= t->B[0];
+    for (int i = 0; i < size; i++) t->B[i] /= norm;
+    for (int i = size; i < kMaxGaussTaps; i++) t->B[i] = 0.f;
+    t->size = size;
+    return size;
+}
+
+// Device-side pipeline on three gray planes already in HBM (A = i0, B = i1, C = i_1), in place.
+// tmp: one scratch plane, part: >= 6*(blocks+1) floats.
+static int preprocess_device(faldoi_ctx *c, float *A, float *B, float *C, float *tmp, float *part, int nx, int ny,
+                             float sigma)
+{
+    GaussTaps taps;
+    const int size = gaussian_taps(sigma, &taps);
+    if (size < 0) return fail(FALDOI_ERR_INVALID, "sigma=%g unsupported", (double)sigma);
+    if (size > nx || size > ny) return fail(FALDOI_ERR_INVALID, "image %dx%d too small for the %d-tap Gaussian", nx, ny, size);
+    const int n = nx * ny;
+    const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    hipStream_t s = c->stream;
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, s, A, B, C, n, part + 6);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, s, part + 6, blocks, part);
+    hipLaunchKernelGGL(normalize3_kernel, dim3(blocks), dim3(256), 0, s, A, B, C, n, part);
+    float *planes[3] = {A, B, C};
+    for (int k = 0; k < 3; ++k) {                     // src/global_faldoi.cpp:2066-2068
+        hipLaunchKernelGGL(gaussian_pass_kernel<false>, dim3(blocks), dim3(256), 0, s, planes[k], tmp, nx, ny, taps);
+        hipLaunchKernelGGL(gaussian_pass_kernel<true>, dim3(blocks), dim3(256), 0, s, tmp, planes[k], nx, ny, taps);
+    }
+    HIP_TRY(hipGetLastError());
+    return FALDOI_OK;
+}
+
+// Host planar image (pd channels) -> gray plane in HBM.  staging: >= 3*n floats of device memory.
+static int upload_gray(faldoi_ctx *c, const float *img, int n, int pd, float *staging, float *dst)
+{
+    if (pd == 1) {
+        HIP_TRY(hipMemcpyAsync(dst, img, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(staging, img, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+        hipLaunchKernelGGL(rgb2gray_kernel, dim3(blocks), dim3(256), 0, c->stream, staging, dst, n);
+        HIP_TRY(hipGetLastError());
+    }
+    return FALDOI_OK;
+}
+
+static int preprocess_check(faldoi_ctx *ctx, const float *i0, const float *i1, int nx, int ny, int pd)
+{
+    if (!ctx || !i0 || !i1) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    if (pd != 1 && pd != 3) return fail(FALDOI_ERR_INVALID, "pd=%d: only gray (1) or RGB (3) planar images", pd);
+    if (nx < 6 || ny < 6 || (long)nx * ny > (1L << 28)) return fail(FALDOI_ERR_INVALID, "image size %dx%d unsupported", nx, ny);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_preprocess_global(faldoi_ctx *ctx, const float *i0, const float *i1, const float *im1, int nx,
+                                        int ny, int pd, float *i0n, float *i1n)
+{
+    int rc = preprocess_check(ctx, i0, i1, nx, ny, pd);
+    if (rc) return rc;
+    if (!i0n || !i1n) return fail(FALDOI_ERR_INVALID, "NULL output");
+    const size_t n = (size_t)nx * ny;
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(float) * (8 * n + 6 * 1026)));
+    float *A = d, *B = d + n, *C = d + 2 * n, *tmp = d + 3 * n, *staging = d + 4 * n, *part = d + 8 * n;
+    rc = upload_gray(ctx, i0, (int)n, pd, staging, A);
+    if (!rc) rc = upload_gray(ctx, i1, (int)n, pd, staging, B);
+    if (!rc) rc = upload_gray(ctx, im1 ? im1 : i1, (int)n, pd, staging, C);     // 2-line list file: I-1 := I1
+    if (!rc) rc = preprocess_device(ctx, A, B, C, tmp, part, nx, ny, 0.90f);  // PRESMOOTHING_SIGMA
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(i0n, A, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(i1n, B, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(FALDOI_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+extern "C" int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
+                                               const float *im1, int pd, const float *u, const float *xi)
+{
+    if (!b || !u) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    if (pair < 0 || pair >= b->npairs) return fail(FALDOI_ERR_INVALID, "pair %d out of range", pair);
+    faldoi_ctx *c = b->ctx;
+    int rc = preprocess_check(c, i0, i1, b->nx, b->ny, pd);
+    if (rc) return rc;
+    const size_t n = (size_t)b->nx * b->ny, nb = n * sizeof(float);
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(float) * (5 * n + 6 * 1026)));
+    float *C = d, *tmp = d + n, *staging = d + 2 * n, *part = d + 5 * n;
+    float *A = plane_ptr(b, pair, P_I0), *B = plane_ptr(b, pair, P_I1);
+    rc = upload_gray(c, i0, (int)n, pd, staging, A);
+    if (!rc) rc = upload_gray(c, i1, (int)n, pd, staging, B);
+    if (!rc) rc = upload_gray(c, im1 ? im1 : i1, (int)n, pd, staging, C);
+    if (!rc) rc = preprocess_device(c, A, B, C, tmp, part, b->nx, b->ny, 0.90f);
+    hipStream_t s = c->stream;
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(plane_ptr(b, pair, P_INIT + 0), u, nb, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(plane_ptr(b, pair, P_INIT + 1), u + n, nb, hipMemcpyHostToDevice, s);
+        for (int k = 0; k < 4 && e == hipSuccess; ++k)
+            e = xi ? hipMemcpyAsync(plane_ptr(b, pair, P_INIT + 2 + k), xi + k * n, nb, hipMemcpyHostToDevice, s)
+                   : hipMemsetAsync(plane_ptr(b, pair, P_INIT + 2 + k), 0, nb, s);
+    }
+    hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(FALDOI_ERR_HIP, "upload failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    b->uploaded[pair] = 1;
+    b->solved = false;
+    return FALDOI_OK;
 }
 
 // ------------------------------------------------------------------------------------------ self-test

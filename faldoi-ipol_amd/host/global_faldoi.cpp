@@ -1,0 +1,118 @@
+// global_faldoi -- drop-in for the reference executable of the same name
+// (src/global_faldoi.cpp:1846-2215) with the variational solve running on an MI355X through the
+// C ABI of libfaldoi_hip.so.
+//
+//   global_faldoi ims.txt in_flow.flo out.flo [-m method] [-w warps] [-p params.txt]
+//                 [-glb_iters n] [-verbose 0|1]
+//   additive flags (defaults = reference behaviour):
+//                 [-max_inner n] [-tol_stop 0|1] [-chunk k] [-gpu id]
+//
+// ims.txt: one path per line: I0, I1 [, I-1, I2].  As in the reference, I-1 is only used when
+// the file has four lines, otherwise I1 takes its place in the normalisation (:1933-1937).
+// Methods: 0 (TV-l2 coupled) and 1 (its weighted id, which the reference's global step maps to the
+// same solver, :2132).  Other functionals are not part of this build and are refused loudly.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "faldoi_hip.h"
+#include "image_io.hpp"
+#include "options.hpp"
+
+using namespace faldoi_host;
+
+static int usage(size_t n)
+{
+    fprintf(stderr, "Without occlusions:\n");
+    fprintf(stderr, "Usage: %zu  ims.txt in_flow.flo  out.flo [-m method_val] [-w num_warps] [-p file of parameters] "
+                    "[-glb_iters global_iters] [-verbose verbose] \n", n);
+    fprintf(stderr, "  MI355X build extras: [-max_inner n] [-tol_stop 0|1] [-chunk k] [-gpu id]\n");
+    return EXIT_FAILURE;
+}
+
+int main(int argc, char *argv[])
+{
+    try {
+        std::vector<std::string> args(argv, argv + argc);
+        const int nwarps = std::stoi(pick_option(args, "w", std::to_string(FALDOI_DEFAULT_WARPS_GLOBAL)));
+        const int method = std::stoi(pick_option(args, "m", "0"));
+        const std::string file_params = pick_option(args, "p", "");
+        (void)pick_option(args, "glb_iters", "400");     // parsed and ignored for methods 0-7, like the reference (:684)
+        const int verbose = std::stoi(pick_option(args, "verbose", "0"));
+        const int max_inner = std::stoi(pick_option(args, "max_inner", std::to_string(FALDOI_DEFAULT_MAX_INNER)));
+        const int tol_stop = std::stoi(pick_option(args, "tol_stop", "1"));
+        const int chunk = std::stoi(pick_option(args, "chunk", "0"));
+        const int gpu = std::stoi(pick_option(args, "gpu", "0"));
+        if (args.size() != 4) return usage(args.size());
+        if (method != 0 && method != 1) {
+            fprintf(stderr, "ERROR: method %d is not available in this build (TV-l2 coupled, -m 0/1, only)\n", method);
+            return 2;
+        }
+
+        std::vector<std::string> files;
+        {
+            std::ifstream in(args[1]);
+            if (!in) { fprintf(stderr, "ERROR: cannot open %s\n", args[1].c_str()); return EXIT_FAILURE; }
+            for (std::string line; std::getline(in, line);) files.push_back(line);
+        }
+        if (files.size() < 2) { fprintf(stderr, "ERROR: %s must list at least two images\n", args[1].c_str()); return EXIT_FAILURE; }
+
+        const Image i0 = read_image_split(files[0]);
+        const Image i1 = read_image_split(files[1]);
+        const bool have_im1 = files.size() == 4;
+        const Image im1 = have_im1 ? read_image_split(files[2]) : Image();
+        const Image flow = read_image_split(args[2]);
+        if (i0.w != i1.w || i0.h != i1.h || i0.pd != i1.pd ||
+            (have_im1 && (im1.w != i0.w || im1.h != i0.h || im1.pd != i0.pd))) {
+            fprintf(stderr, "ERROR: input images and flow size mismatch\n");
+            return EXIT_FAILURE;
+        }
+        if (flow.w != i0.w || flow.h != i0.h || flow.pd != 2) {
+            fprintf(stderr, "ERROR: input flow field size mismatch\n");
+            return EXIT_FAILURE;
+        }
+        const int pd = i0.pd == 1 ? 1 : 3;               // rgb2gray reads the first three planes (:1820)
+        if (i0.pd == 2) { fprintf(stderr, "ERROR: two-channel images are not supported\n"); return EXIT_FAILURE; }
+
+        const EnergyParams ep = read_energy_params(file_params);
+        faldoi_tvl1_params prm;
+        faldoi_tvl1_default_params(&prm);
+        prm.lambda = ep.lambda; prm.theta = ep.theta; prm.tau = ep.tau; prm.tol = ep.tol;
+        prm.warps = nwarps; prm.max_inner = max_inner; prm.tol_stop = tol_stop; prm.chunk = chunk; prm.verbose = verbose;
+
+        faldoi_ctx *ctx = nullptr;
+        faldoi_tvl1_batch *batch = nullptr;
+        auto die = [&](const char *what) {
+            fprintf(stderr, "ERROR: %s: %s\n", what, faldoi_last_error());
+            if (batch) faldoi_tvl1_batch_destroy(batch);
+            if (ctx) faldoi_ctx_destroy(ctx);
+            return 3;
+        };
+        if (faldoi_ctx_create(gpu, &ctx)) return die("no usable GPU");
+        if (faldoi_tvl1_batch_create(ctx, 1, i0.w, i0.h, &batch)) return die("allocation");
+        if (faldoi_tvl1_batch_upload_images(batch, 0, i0.data.data(), i1.data.data(), have_im1 ? im1.data.data() : nullptr,
+                                            pd, flow.data.data(), nullptr))
+            return die("upload");
+        std::vector<int> iters(nwarps);
+        std::vector<float> errs(nwarps);
+        faldoi_tvl1_stats st{};
+        st.iters_cap = nwarps; st.iters = iters.data(); st.err = errs.data();
+        if (faldoi_tvl1_batch_solve(batch, &prm, &st)) return die("solve");
+        std::vector<float> u(2 * (size_t)i0.w * i0.h);
+        if (faldoi_tvl1_batch_download(batch, 0, u.data(), nullptr)) return die("download");
+        if (verbose)
+            std::cout << "(tvl2OF) All tasks took " << st.solve_ms * 1e-3 << " (device, " << st.total_iters
+                      << " inner iterations)" << std::endl;
+        write_flo(args[3], u.data(), i0.w, i0.h);
+        faldoi_tvl1_batch_destroy(batch);
+        faldoi_ctx_destroy(ctx);
+        return EXIT_SUCCESS;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ERROR: %s\n", e.what());
+        return EXIT_FAILURE;
+    }
+}

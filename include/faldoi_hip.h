@@ -131,6 +131,20 @@ int faldoi_divergence(faldoi_ctx *ctx, const float *v1, const float *v2, float *
 int faldoi_bicubic_warp(faldoi_ctx *ctx, const float *in, const float *u, const float *v, float *out,
                         int nx, int ny, int border_out);
 
+/* ---------------------------------------------------------------- preprocessing
+ * Replaces the image preparation in global_faldoi's main, src/global_faldoi.cpp:2049-2068:
+ * rgb2gray (:1820) -> image_normalization_3 (src/utils.cpp:743, call-site binding of :2065)
+ * -> gaussian(sigma = PRESMOOTHING_SIGMA = 0.9) (src/utils.cpp:521), on the device.
+ * i0, i1, im1: planar images with pd channels (1 = gray, 3 = R,G,B planes; iio's "split" layout),
+ * values as read from file (0..255).  im1 = I(-1); NULL means "use i1", which is what the
+ * reference does for a 2-line list file (:1933-1937).  Outputs: nx*ny planes the solver takes. */
+int faldoi_preprocess_global(faldoi_ctx *ctx, const float *i0, const float *i1, const float *im1,
+                             int nx, int ny, int pd, float *i0n, float *i1n);
+/* Same preparation straight into a batch slot (images never return to the host) plus the
+ * initial flow u (2 planes) and duals xi (4 planes or NULL = zero), as faldoi_tvl1_batch_upload. */
+int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
+                                    const float *im1, int pd, const float *u, const float *xi);
+
 /* ---------------------------------------------------------------- self-test
  * The kernels replace the IEEE fp32 divide on two call sites by an fp64-assisted sequence that
  * is proven to return the same bits (csrc/faldoi_device.hpp).  This entry point checks the claim

@@ -64,6 +64,39 @@ def test_bicubic_warp_bit_exact_incl_out_of_range(ctx, oracle, border_out):
     assert bits_equal(got, want), mismatch_report(got, want)
 
 
+# ------------------------------------------------------------------ preprocessing
+def test_preprocessing_bit_exact_sintel_and_random(ctx, oracle):
+    i0, i1 = sintel_pair()
+    g0, g1 = ctx.preprocess_global(i0, i1)
+    o0, o1 = oracle.preprocess_global(i0, i1)
+    assert bits_equal(g0, o0), mismatch_report(g0, o0)
+    assert bits_equal(g1, o1), mismatch_report(g1, o1)
+    rng = np.random.default_rng(5)
+    for pd, h, w in ((1, 6, 6), (3, 17, 9), (1, 50, 300), (3, 64, 64)):
+        a, b, c = (np.floor(rng.random((pd, h, w)) * 256).astype(np.float32) for _ in range(3))
+        c += 3.0                                   # distinct minima: exercises the min-selection quirk
+        g0, g1 = ctx.preprocess_global(a, b, c)
+        o = [np.empty((h, w), np.float32) for _ in range(3)]
+        oracle.lib().orc_preprocess_global(a, b, c, w, h, pd, o[0], o[1], o[2])
+        assert bits_equal(g0, o[0]) and bits_equal(g1, o[1]), (pd, h, w)
+    with pytest.raises(F.FaldoiError):
+        ctx.preprocess_global(np.zeros((2, 8, 8), np.float32), np.zeros((2, 8, 8), np.float32))
+    with pytest.raises(F.FaldoiError):
+        ctx.preprocess_global(np.zeros((1, 4, 8), np.float32), np.zeros((1, 4, 8), np.float32))
+
+
+def test_upload_images_then_solve_matches_known_answer(ctx):
+    # the whole device-side data path of global_faldoi: RGB frames -> preprocessing -> solver
+    case = known_answers()["sintel_clean_easy_f2_f3_crop_400_150_128x96_zero_init"]
+    i0, i1 = sintel_pair((case["x0"], case["y0"], case["w"], case["h"]))
+    b = F.Tvl1Batch(ctx, 1, case["w"], case["h"])
+    b.upload_images(0, i0, i1, np.zeros((2, case["h"], case["w"]), np.float32))
+    iters, errs, ms, nl = b.solve()
+    assert list(iters[0]) == case["iters"]
+    assert flo_sha256(b.download(0)).startswith(case["flo_sha256_prefix"])
+    b.close()
+
+
 def test_fp64_assisted_quotient_equals_ieee_divide(ctx):
     # 2^30 hashed samples x 2 call sites, all exponents incl. subnormals and tie makers
     assert ctx.selftest_division(count=1 << 30, seed=1) == 0
@@ -198,3 +231,23 @@ def test_argument_errors_are_reported_not_fatal(ctx):
     with pytest.raises(F.FaldoiError):
         b.solve(tau=-1.0)
     b.close()
+
+
+def test_global_faldoi_cli_reproduces_the_reference_flo(ctx, tmp_path):
+    # The drop-in itself: `global_faldoi ims.txt zero.flo out.flo -w 5 -verbose 1` on the reference's
+    # example frames must write the .flo the compiled reference wrote (sha256 recorded in SURVEY.md
+    # App. D) and print the reference's per-warp iteration counts.
+    import subprocess
+    case = known_answers()["sintel_clean_easy_f2_f3_zero_init"]
+    bins = F.build.build_host()
+    ims = tmp_path / "ims.txt"
+    ims.write_text(GOLDEN + "/sintel_clean_easy_frame_0002.png\n" + GOLDEN + "/sintel_clean_easy_frame_0003.png\n")
+    z, out = tmp_path / "zero.flo", tmp_path / "out.flo"
+    F.flo.write_flo(str(z), np.zeros((2, 436, 1024), np.float32))
+    r = subprocess.run([bins["global_faldoi"], str(ims), str(z), str(out), "-w", "5", "-verbose", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    import hashlib
+    assert hashlib.sha256(out.read_bytes()).hexdigest().startswith(case["flo_sha256_prefix"])
+    lines = [l for l in r.stderr.splitlines() if l.startswith("Warping:")]
+    assert [int(l.split("Iter:")[1].split()[0]) for l in lines] == case["iters"]

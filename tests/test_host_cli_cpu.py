@@ -1,0 +1,104 @@
+"""CPU suite, part 4: the host-side executables (the reference's command-line surface) -- image
+decoders against PIL, sparse_flow against its definition, global_faldoi's argument handling."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import faldoi_ipol_amd as F
+from util import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def bins():
+    return F.build.build_host()
+
+
+def _fnv(b):
+    a = np.frombuffer(b, np.uint8)
+    h = 1469598103934665603
+    for x in a.tolist():
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def _info(bins, path):
+    out = subprocess.run([bins["faldoi_imginfo"], str(path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    w, h, pd, hx = out.stdout.split()
+    return int(w), int(h), int(pd), hx
+
+
+def test_png_decoder_matches_pil(bins, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    cases = []
+    rgb = rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "rgb.png"); cases.append(("rgb.png", rgb.transpose(2, 0, 1)))
+    gray = rng.integers(0, 256, (9, 31), dtype=np.uint8)
+    Image.fromarray(gray, "L").save(tmp_path / "gray.png"); cases.append(("gray.png", gray[None]))
+    rgba = rng.integers(0, 256, (7, 5, 4), dtype=np.uint8)
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "rgba.png"); cases.append(("rgba.png", rgba.transpose(2, 0, 1)))
+    g16 = rng.integers(0, 65536, (6, 8), dtype=np.uint16)
+    Image.fromarray(g16, "I;16").save(tmp_path / "g16.png"); cases.append(("g16.png", g16[None]))
+    pal = Image.fromarray(rgb, "RGB").quantize(16)
+    pal.save(tmp_path / "pal.png"); cases.append(("pal.png", np.asarray(pal.convert("RGB")).transpose(2, 0, 1)))
+    with open(tmp_path / "a.ppm", "wb") as f:
+        f.write(b"P6\n# c\n17 13\n255\n" + rgb.tobytes())
+    cases.append(("a.ppm", rgb.transpose(2, 0, 1)))
+    for name, planes in cases:
+        want = np.ascontiguousarray(planes, dtype=np.float32)
+        w, h, pd, hx = _info(bins, tmp_path / name)
+        assert (pd, h, w) == want.shape, name
+        assert hx == _fnv(want.tobytes()), name
+    # the committed Sintel frame (interesting filters: a real-world encoder)
+    frame = os.path.join(GOLDEN, "sintel_clean_easy_frame_0003.png")
+    want = np.asarray(Image.open(frame).convert("RGB"), np.float32).transpose(2, 0, 1)
+    w, h, pd, hx = _info(bins, frame)
+    assert (w, h, pd) == (1024, 436, 3)
+    assert hx == _fnv(np.ascontiguousarray(want).tobytes())
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"\x89PNG\r\n\x1a\nxxxx")
+    assert subprocess.run([bins["faldoi_imginfo"], str(bad)], capture_output=True).returncode == 1
+
+
+def test_sparse_flow_cli(bins, tmp_path):
+    m = tmp_path / "m.txt"
+    m.write_text("1.5 2.25 4.0 1.0\n0 0 -1 -2 extra columns ignored\n50 50 1 1\nnot a match\n6.9 3.1 7.9 3.6\n")
+    out = tmp_path / "s.flo"
+    r = subprocess.run([bins["sparse_flow"], str(m), "8", "5", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    f = F.flo.read_flo(str(out))
+    assert f.shape == (2, 5, 8)
+    want = np.full((2, 5, 8), np.nan, np.float32)
+    want[:, 2, 1] = (2.5, -1.25)
+    want[:, 0, 0] = (-1.0, -2.0)
+    want[:, 3, 6] = (1.0, 0.5)                      # (50,50) is outside 8x5 and skipped
+    assert np.array_equal(np.isnan(f), np.isnan(want))
+    assert np.array_equal(f[~np.isnan(f)], want[~np.isnan(want)])
+    assert subprocess.run([bins["sparse_flow"], str(m)], capture_output=True).returncode == 1
+
+
+def test_global_faldoi_cli_argument_handling(bins, tmp_path):
+    exe = bins["global_faldoi"]
+    r = subprocess.run([exe, "only_one_arg"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage" in r.stderr
+    ims = tmp_path / "ims.txt"
+    ims.write_text(os.path.join(GOLDEN, "sintel_clean_easy_frame_0002.png") + "\n"
+                   + os.path.join(GOLDEN, "sintel_clean_easy_frame_0003.png") + "\n")
+    z = tmp_path / "zero.flo"
+    F.flo.write_flo(str(z), np.zeros((2, 436, 1024), np.float32))
+    # option pairs may sit anywhere; unsupported functionals are refused, not silently replaced
+    r = subprocess.run([exe, "-m", "6", str(ims), str(z), str(tmp_path / "o.flo")], capture_output=True, text=True)
+    assert r.returncode == 2 and "not available" in r.stderr
+    small = tmp_path / "small.flo"
+    F.flo.write_flo(str(small), np.zeros((2, 4, 4), np.float32))
+    r = subprocess.run([exe, str(ims), str(small), str(tmp_path / "o.flo")], capture_output=True, text=True)
+    assert r.returncode == 1 and "flow field size mismatch" in r.stderr
+    import ctypes
+    n = ctypes.c_int(0)
+    if F.capi.lib().faldoi_device_count(ctypes.byref(n)) != 0:       # CI container: no GPU, no fallback
+        r = subprocess.run([exe, str(ims), str(z), str(tmp_path / "o.flo")], capture_output=True, text=True)
+        assert r.returncode == 3 and "no usable GPU" in r.stderr
+        assert not (tmp_path / "o.flo").exists()
