@@ -23,6 +23,9 @@ WARPS, INNER = 300, 10
 BYTES_PER_PX_ITER = 76        # 19 fp32 planes touched once per inner iteration
 BYTES_PER_PX_WARP = 44        # per outer warp (bicubic gathers + constants)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# HBM bytes per launch of tvl1_chunk_kernel from rocprofv3 PMC passes (profiles/): filled in from the
+# committed counter summaries; None until measured for the current kernel.
+TRAFFIC_BYTES_PER_LAUNCH = None
 
 
 def main():
@@ -98,14 +101,27 @@ def main():
     px_iters_local = float(args.steps) * npairs * W * H * WARPS * INNER
     dt_max, px_iters = F.shard.reduce_timing(dt, px_iters_local, dist if world > 1 else None, dev)
 
+    # Duration of the dominant kernel itself (outside the timed region): one more solve with a HIP
+    # event pair around every launch of the fused iteration kernel, on the library's own stream.
+    kernel_us = None
+    if rank == 0:
+        os.environ["FALDOI_EVENT_TIMING"] = "1"
+        step()
+        os.environ["FALDOI_EVENT_TIMING"] = "0"
+        _, nl1, _, chunk_ms = batch.last_timing()
+        if chunk_ms > 0:
+            kernel_us = chunk_ms * 1e3 / nl1
+
     out = None
     if rank == 0:
         value = px_iters / dt_max / 1e6
-        launch_ms = dev_ms / max(launches, 1)
-        iters_per_launch = WARPS * INNER * args.steps / max(launches / 1, 1) if launches else 0
-        bytes_per_launch = npairs * W * H * (BYTES_PER_PX_ITER * (WARPS * INNER * args.steps / launches)
-                                             + BYTES_PER_PX_WARP * (WARPS * args.steps / launches))
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        iters_per_launch = WARPS * INNER * args.steps / launches
+        # dominant kernel = tvl1_chunk_kernel: algorithmic bytes of the inner iterations one launch
+        # advances (76 B/px/iteration) over that launch's own duration
+        bytes_per_launch = npairs * W * H * BYTES_PER_PX_ITER * iters_per_launch
+        group_us = dev_ms * 1e3 / launches                 # whole solve / launches (incl. the per-warp kernel)
+        launch_us = kernel_us if kernel_us else group_us
+        achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
         out = {
             "metric": "Mpixels*warp-iters/sec on TV-L1 global_faldoi, Sintel 1024x436; EPE vs CPU ref",
             "value": round(value, 1), "unit": "Mpx*iter/s", "n_gpus": world, "steps": args.steps,
@@ -118,8 +134,10 @@ def main():
                        "pairs_per_gpu": npairs, "parallelism": "pairs-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "tvl1_chunk_kernel",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "launch_us": round(launch_ms * 1e3, 2),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                         "launch_us": round(launch_us, 2), "launch_us_source":
+                             "HIP event pair around every launch" if kernel_us else "solve time / launches",
+                         "solve_us_per_launch_incl_warp_kernel": round(group_us, 2),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "inner_iters_per_launch": round(iters_per_launch, 2)},
         }

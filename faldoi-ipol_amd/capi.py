@@ -83,7 +83,7 @@ def lib():
     L.faldoi_tvl1_batch_solve.argtypes = [vp, C.POINTER(Tvl1Params), C.POINTER(Tvl1Stats)]
     L.faldoi_tvl1_batch_download.argtypes = [vp, C.c_int, _F, vp]
     L.faldoi_tvl1_batch_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int),
-                                                C.POINTER(C.c_long)]
+                                                C.POINTER(C.c_long), C.POINTER(C.c_double)]
     L.faldoi_centered_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_forward_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_divergence.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
@@ -245,9 +245,9 @@ class Tvl1Batch:
         return iters, errs, stats[0].solve_ms, stats[0].chunk_launches
 
     def last_timing(self):
-        ms, nl, pi = C.c_double(), C.c_int(), C.c_long()
-        _check(lib().faldoi_tvl1_batch_last_timing(self._h, C.byref(ms), C.byref(nl), C.byref(pi)))
-        return ms.value, nl.value, pi.value
+        ms, nl, pi, cms = C.c_double(), C.c_int(), C.c_long(), C.c_double()
+        _check(lib().faldoi_tvl1_batch_last_timing(self._h, C.byref(ms), C.byref(nl), C.byref(pi), C.byref(cms)))
+        return ms.value, nl.value, pi.value, cms.value
 
     def download(self, pair, want_xi=False):
         u = np.empty((2, self.h, self.w), np.float32)

@@ -64,8 +64,10 @@ struct faldoi_tvl1_batch {
     std::vector<char> uploaded;
     bool solved = false;
     double last_ms = 0.0;
+    double last_chunk_ms = 0.0;       // sum of per-launch event times of the fused kernel (0 = not measured)
     int last_launches = 0;
     long last_px_iters = 0;
+    std::vector<hipEvent_t> ev;       // per-launch event pairs (only when FALDOI_EVENT_TIMING=1)
 };
 
 static int check_device(int *count)
@@ -245,6 +247,7 @@ extern "C" void faldoi_tvl1_batch_destroy(faldoi_tvl1_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
+    for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->slabs) (void)hipFree(b->slabs);
     if (b->ctl) (void)hipFree(b->ctl);
     if (b->err_part) (void)hipFree(b->err_part);
@@ -378,6 +381,19 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
         HIP_TRY(hipGetLastError());
     }
 
+    // Optional per-launch timing of the fused kernel: one HIP event pair around every launch on the
+    // context's stream (FALDOI_EVENT_TIMING=1; static schedule only).  Off by default: the events
+    // add a little stream traffic, so the headline wall-clock is taken without them.
+    const bool ev_timing = !dynamic && getenv("FALDOI_EVENT_TIMING") && atoi(getenv("FALDOI_EVENT_TIMING")) > 0;
+    size_t ev_used = 0;
+    if (ev_timing) {
+        const size_t need = 2 * (size_t)warps * ((prm->max_inner + chunk - 1) / chunk);
+        while (b->ev.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            b->ev.push_back(e);
+        }
+    }
     if (!dynamic) {
         int cur = 0;
         int last_iters = chunk;
@@ -390,8 +406,10 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
                                        b->npairs, b->ctl, 1, cur);
                     HIP_TRY(hipGetLastError());
                 }
+                if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
                 HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
                                      b->ctl, b->err_part, 1, cur, it, w));
+                if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
                 ++launches;
                 cur ^= 1;
                 n += it;
@@ -432,6 +450,12 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
     HIP_TRY(hipEventSynchronize(c->ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    double chunk_ms = 0.0;
+    for (size_t i = 0; i + 1 < ev_used; i += 2) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, b->ev[i], b->ev[i + 1]));
+        chunk_ms += t;
+    }
 
     std::vector<int> h_it((size_t)warps * b->npairs);
     std::vector<float> h_er((size_t)warps * b->npairs);
@@ -461,18 +485,21 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
     }
     b->solved = true;
     b->last_ms = ms;
+    b->last_chunk_ms = chunk_ms;
     b->last_launches = launches;
     b->last_px_iters = px_iters;
     return FALDOI_OK;
 }
 
-extern "C" int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *chunk_launches, long *px_iters)
+extern "C" int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *chunk_launches, long *px_iters,
+                                             double *chunk_kernel_ms)
 {
     if (!b) return fail(FALDOI_ERR_INVALID, "batch is NULL");
     if (!b->solved) return fail(FALDOI_ERR_STATE, "no solve has completed");
     if (solve_ms) *solve_ms = b->last_ms;
     if (chunk_launches) *chunk_launches = b->last_launches;
     if (px_iters) *px_iters = b->last_px_iters;
+    if (chunk_kernel_ms) *chunk_kernel_ms = b->last_chunk_ms;
     return FALDOI_OK;
 }
 

@@ -113,10 +113,13 @@ int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm,
                             faldoi_tvl1_stats *stats);
 /* HBM -> host.  u: 2*nx*ny; xi: 4*nx*ny or NULL. */
 int faldoi_tvl1_batch_download(faldoi_tvl1_batch *b, int pair, float *u, float *xi);
-/* Device time (ms) and launch count of the fused iteration kernel accumulated by the last
- * batch_solve, measured with HIP events on the context's stream around every launch group. */
+/* Timing of the last batch_solve, from HIP events recorded on the context's own stream:
+ * solve_ms = the whole solve; chunk_launches / px_iters = launches of the fused iteration kernel
+ * and pixel-iterations they advanced; chunk_kernel_ms = sum over those launches of the time
+ * between an event pair placed around each one (measured only when the environment variable
+ * FALDOI_EVENT_TIMING=1 is set and tol_stop == 0; otherwise 0).  Any pointer may be NULL. */
 int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *chunk_launches,
-                                  long *px_iters);
+                                  long *px_iters, double *chunk_kernel_ms);
 
 /* ---------------------------------------------------------------- primitives (host buffers)
  * Stand-alone launches of the device functions the fused kernel is made of, for stage-level
