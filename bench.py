@@ -52,9 +52,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev)               # "nccl" is RCCL on ROCm
 
     npairs = args.pairs_per_gpu
     ctx = F.Context(local_rank)
@@ -84,7 +86,7 @@ def main():
         step()
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -99,7 +101,7 @@ def main():
     dt = time.perf_counter() - t0
 
     px_iters_local = float(args.steps) * npairs * W * H * WARPS * INNER
-    dt_max, px_iters = F.shard.reduce_timing(dt, px_iters_local, dist if world > 1 else None, dev)
+    dt_max, px_iters = F.shard.reduce_timing(dt, px_iters_local, dist if use_dist else None, dev)
 
     # Duration of the dominant kernel itself (outside the timed region): one more solve with a HIP
     # event pair around every launch of the fused iteration kernel, on the library's own stream.
@@ -159,7 +161,7 @@ def main():
         print(json.dumps(out), flush=True)
     batch.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -217,26 +217,24 @@ __device__ __forceinline__ float grad_sq(float I1wx, float I1wy)
 }
 
 // :690-718 thresholding step: v = u + TH(rho, grad).
-__device__ __forceinline__ void threshold_step(float rho_c, float I1wx, float I1wy, float grad,
+// rgrad = recip_f64(grad), constant over a launch; the reference's `fi = -rho / grad` is obtained
+// as the exact quotient div_by(-rho, grad, rgrad) (grad >= 1e-8 > 0 wherever fi is selected; for
+// smaller grad the value is computed but discarded).  Branch-free: one selected factor f with
+// d = f * I1w{x,y}; the three explicit factors are the reference's own operands (l_t, -l_t, fi).
+__device__ __forceinline__ void threshold_step(float rho_c, float I1wx, float I1wy, float grad, double rgrad,
                                                float u1, float u2, float l_t, float &v1, float &v2)
 {
     const float rho = rho_c + (I1wx * u1 + I1wy * u2);
     const float lg = l_t * grad;
-    float d1, d2;
-    if (rho < -lg) {                 // (-l_t)*grad == -(l_t*grad) exactly
-        d1 = l_t * I1wx;
-        d2 = l_t * I1wy;
-    } else if (rho > lg) {
-        d1 = -l_t * I1wx;
-        d2 = -l_t * I1wy;
-    } else if (grad < grad_zero_bound()) {
-        d1 = 0.0f;
-        d2 = 0.0f;
-    } else {
-        const float fi = -rho / grad;
-        d1 = fi * I1wx;
-        d2 = fi * I1wy;
-    }
+    const bool below = rho < -lg;                 // (-l_t)*grad == -(l_t*grad) exactly
+    const bool above = rho > lg;
+    const float fi = div_by(-rho, grad, rgrad);
+    const float f = below ? l_t : (above ? -l_t : fi);
+    float d1 = f * I1wx;
+    float d2 = f * I1wy;
+    const bool flat = !below && !above && (grad < grad_zero_bound());
+    d1 = flat ? 0.0f : d1;                        // `d1 = d2 = 0` (:706), not a product: keeps +0
+    d2 = flat ? 0.0f : d2;
     v1 = u1 + d1;
     v2 = u2 + d2;
 }

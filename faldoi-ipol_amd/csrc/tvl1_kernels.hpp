@@ -306,6 +306,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
     const float *iwyp = slab + (size_t)P_IWY * plane_elems;
 
     float u1[R], u2[R], ub1[R], ub2[R], x11[R], x12[R], x21[R], x22[R], rc[R], ix[R], iy[R], gr[R];
+    double rgr[R];                               // fp64 reciprocal of |grad I|^2, constant over the launch
     bool in[R], own[R];
 
 #pragma unroll
@@ -326,6 +327,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
         ix[r] = in[r] ? iwxp[p] : 0.0f;
         iy[r] = in[r] ? iwyp[p] : 0.0f;
         gr[r] = grad_sq(ix[r], iy[r]);                          // src/global_faldoi.cpp:648-652
+        rgr[r] = recip_f64(gr[r]);
     }
 
     for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;
@@ -386,7 +388,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
                     div2 = (x21[r] - l21) + (x22[r] - t22);
                 }
                 float v1, v2;
-                threshold_step(rc[r], ix[r], iy[r], gr[r], u1[r], u2[r], prm.l_t, v1, v2);
+                threshold_step(rc[r], ix[r], iy[r], gr[r], rgr[r], u1[r], u2[r], prm.l_t, v1, v2);
                 const float e = primal_step(u1[r], u2[r], ub1[r], ub2[r], v1, v2, div1, div2, prm.theta,
                                             prm.rtheta, prm.tau);
                 emax = (own[r] && e > emax) ? e : emax;

@@ -14,7 +14,7 @@ def assign_pairs(npairs, world, rank):
 
 def reduce_timing(local_seconds, local_units, dist=None, device=None):
     """Returns (max seconds over ranks, total units over ranks)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(local_seconds), float(local_units)
     import torch
     t = torch.tensor([float(local_seconds)], dtype=torch.float64, device=device)
