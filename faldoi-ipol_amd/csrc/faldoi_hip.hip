@@ -179,21 +179,21 @@ static TileCfg pick_tile()
 template <int R, int NW>
 static hipError_t launch_chunk_t(dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int ntx, int nty,
                                  int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st, int cur,
-                                 int iters, int slot)
+                                 int first, int iters, int slot)
 {
     hipLaunchKernelGGL((tvl1_chunk_kernel<R, NW>), grid, dim3(64 * NW), 0, s, base, pe, nx, ny, ntx, nty, npairs, halo,
-                       prm, ctl, err, st, cur, iters, slot);
+                       prm, ctl, err, st, cur, first, iters, slot);
     return hipGetLastError();
 }
 
 static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int ntx,
                                int nty, int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st,
-                               int cur, int iters, int slot)
+                               int cur, int first, int iters, int slot)
 {
 #define FALDOI_CASE(r, w)                                                                                             \
     if (tc.R == r && tc.NW == w)                                                                                      \
-        return launch_chunk_t<r, w>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, iters, \
-                                    slot);
+        return launch_chunk_t<r, w>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, first, \
+                                    iters, slot);
     FALDOI_CASE(4, 16)
     FALDOI_CASE(4, 14)
     FALDOI_CASE(4, 12)
@@ -208,6 +208,17 @@ static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base
     FALDOI_CASE(2, 16)
 #undef FALDOI_CASE
     return hipErrorInvalidValue;
+}
+
+static void launch_warp(int variant, dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int npairs,
+                        const PairCtl *ctl, int st, int cur)
+{
+    if (variant == 8)
+        hipLaunchKernelGGL(tvl1_warp_kernel<8>, grid, dim3(256), 0, s, base, pe, nx, ny, npairs, ctl, st, cur);
+    else if (variant == 6)
+        hipLaunchKernelGGL(tvl1_warp_kernel<6>, grid, dim3(256), 0, s, base, pe, nx, ny, npairs, ctl, st, cur);
+    else
+        hipLaunchKernelGGL(tvl1_warp_kernel<4>, grid, dim3(256), 0, s, base, pe, nx, ny, npairs, ctl, st, cur);
 }
 
 // ------------------------------------------------------------------------------------------ batch
@@ -366,6 +377,8 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
 
     const int npix = b->nx * b->ny;
     const dim3 wgrid(((npix + 255) / 256) * b->npairs);
+    int wvariant = 4;                                  // waves/SIMD the per-warp kernel is compiled for
+    if (const char *v = getenv("FALDOI_WARP_WPS")) wvariant = atoi(v);
     int launches = 0;
     HIP_TRY(hipEventRecord(c->ev0, s));
     HIP_TRY(hipMemsetAsync(b->d_done, 0, sizeof(int), s));
@@ -402,13 +415,12 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
             while (n < prm->max_inner) {
                 const int it = (prm->max_inner - n) < chunk ? (prm->max_inner - n) : chunk;
                 if (n == 0) {
-                    hipLaunchKernelGGL(tvl1_warp_kernel, wgrid, dim3(256), 0, s, b->slabs, b->plane_elems, b->nx, b->ny,
-                                       b->npairs, b->ctl, 1, cur);
+                    launch_warp(wvariant, wgrid, s, b->slabs, b->plane_elems, b->nx, b->ny, b->npairs, b->ctl, 1, cur);
                     HIP_TRY(hipGetLastError());
                 }
                 if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
                 HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
-                                     b->ctl, b->err_part, 1, cur, it, w));
+                                     b->ctl, b->err_part, 1, cur, n == 0, it, w));
                 if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
                 ++launches;
                 cur ^= 1;
@@ -426,11 +438,10 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
         const long max_launches = 2L * warps * ((prm->max_inner + chunk - 1) / chunk + 1) + group;
         for (;;) {
             for (int g = 0; g < group; ++g) {
-                hipLaunchKernelGGL(tvl1_warp_kernel, wgrid, dim3(256), 0, s, b->slabs, b->plane_elems, b->nx, b->ny,
-                                   b->npairs, b->ctl, 0, 0);
+                launch_warp(wvariant, wgrid, s, b->slabs, b->plane_elems, b->nx, b->ny, b->npairs, b->ctl, 0, 0);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
-                                     b->ctl, b->err_part, 0, 0, 0, 0));
+                                     b->ctl, b->err_part, 0, 0, 0, 0, 0));
                 hipLaunchKernelGGL(tvl1_ctl_kernel, dim3(b->npairs), dim3(256), 0, s, b->ctl, b->err_part, ntiles, k,
                                    b->d_iters, b->d_err, b->d_done);
                 HIP_TRY(hipGetLastError());

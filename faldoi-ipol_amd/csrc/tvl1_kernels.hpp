@@ -216,13 +216,14 @@ __global__ void reset_state_kernel(float *__restrict__ base, size_t plane_elems,
 
 // ---------------------------------------------------------------------------------------------
 // Per-warp kernel: bicubic warp of I1, I1x, I1y by the current flow (border_out = true), the
-// per-warp constants rho_c / I1wx / I1wy, and ubar := u  (src/global_faldoi.cpp:635-660).
+// per-warp constants rho_c / I1wx / I1wy  (src/global_faldoi.cpp:635-657).
 // Pointwise in the flow, so it runs once per pixel (no halo).  In dynamic mode a pair takes part
 // only when its control block says the next chunk starts a warp.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 8) void tvl1_warp_kernel(float *__restrict__ base, size_t plane_elems, int nx, int ny,
-                                                        int npairs, const PairCtl *__restrict__ ctl, int static_mode,
-                                                        int s_cur)
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void tvl1_warp_kernel(float *__restrict__ base, size_t plane_elems, int nx, int ny,
+                                                          int npairs, const PairCtl *__restrict__ ctl, int static_mode,
+                                                          int s_cur)
 {
     const int npix = nx * ny;
     const int per_pair = (npix + 255) / 256;                   // blocks per pair
@@ -257,8 +258,7 @@ __global__ __launch_bounds__(256, 8) void tvl1_warp_kernel(float *__restrict__ b
     slab[(size_t)P_RC * plane_elems + p] = rho_const(w0, wx, wy, u1, u2, I0[p]);
     slab[(size_t)P_IWX * plane_elems + p] = wx;
     slab[(size_t)P_IWY * plane_elems + p] = wy;
-    st[2 * plane_elems + p] = u1;                               // ubar = u (:659-660)
-    st[3 * plane_elems + p] = u2;
+    // ubar = u (:659-660) is not materialised: the first chunk of a warp takes ubar from u.
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -283,7 +283,7 @@ template <int R, int NW, bool BORDER>
 __device__ __forceinline__ void tvl1_chunk_body(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int npairs, int ntiles, int t,
     int pair, int txi, int tyi, int halo, const TvConst &prm, float *__restrict__ err_out,
-    int cur, int iters, int err_slot,
+    int cur, int first, int iters, int err_slot,
     float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW], float (*s_x22)[kTileW],
     unsigned (*s_err)[kTileW])
 {
@@ -317,8 +317,6 @@ __device__ __forceinline__ void tvl1_chunk_body(
         const int p = in[r] ? gy * nx + gx : 0;
         u1[r] = in[r] ? src[0 * plane_elems + p] : 0.0f;
         u2[r] = in[r] ? src[1 * plane_elems + p] : 0.0f;
-        ub1[r] = in[r] ? src[2 * plane_elems + p] : 0.0f;
-        ub2[r] = in[r] ? src[3 * plane_elems + p] : 0.0f;
         x11[r] = in[r] ? src[4 * plane_elems + p] : 0.0f;
         x12[r] = in[r] ? src[5 * plane_elems + p] : 0.0f;
         x21[r] = in[r] ? src[6 * plane_elems + p] : 0.0f;
@@ -328,6 +326,17 @@ __device__ __forceinline__ void tvl1_chunk_body(
         iy[r] = in[r] ? iwyp[p] : 0.0f;
         gr[r] = grad_sq(ix[r], iy[r]);                          // src/global_faldoi.cpp:648-652
         rgr[r] = recip_f64(gr[r]);
+    }
+    if (first) {                                                // start of a warp: ubar = u (:659-660)
+#pragma unroll
+        for (int r = 0; r < R; ++r) { ub1[r] = u1[r]; ub2[r] = u2[r]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = in[r] ? (gy0 + r) * nx + gx : 0;
+            ub1[r] = in[r] ? src[2 * plane_elems + p] : 0.0f;
+            ub2[r] = in[r] ? src[3 * plane_elems + p] : 0.0f;
+        }
     }
 
     for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;
@@ -436,7 +445,7 @@ template <int R, int NW>
 __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int ntx, int nty, int npairs,
     int halo, TvConst prm, const PairCtl *__restrict__ ctl, float *__restrict__ err_out,
-    int static_mode, int s_cur, int s_iters, int err_slot)
+    int static_mode, int s_cur, int s_first, int s_iters, int err_slot)
 {
     constexpr int TH = R * NW;
     __shared__ float s_ub1[NW][kTileW];
@@ -453,12 +462,12 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     const int tile = t - pair * ntiles;
     const int tyi = tile / ntx, txi = tile - tyi * ntx;
 
-    int cur, iters;
+    int cur, first, iters;
     if (static_mode) {
-        cur = s_cur; iters = s_iters;
+        cur = s_cur; first = s_first; iters = s_iters;
     } else {
         const PairCtl c = ctl[pair];
-        cur = c.cur; iters = c.iters;
+        cur = c.cur; first = c.first; iters = c.iters;
     }
     if (iters <= 0) return;                     // uniform across the block
 
@@ -467,10 +476,10 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     const bool border = X0 <= 0 || X0 + kTileW >= nx || Y0 <= 0 || Y0 + TH >= ny;
     if (border)
         tvl1_chunk_body<R, NW, true>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out,
-                                     cur, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err);
+                                     cur, first, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err);
     else
         tvl1_chunk_body<R, NW, false>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out,
-                                      cur, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err);
+                                      cur, first, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err);
 }
 
 // ---------------------------------------------------------------------------------------------
