@@ -8,5 +8,5 @@ build.py    in-tree hipcc build
 The directory name follows the upstream project and is not a Python identifier; import it as
 `faldoi_ipol_amd` (the loader shim faldoi_ipol_amd.py at the repository root does that).
 """
-from . import build, capi, flo, shard  # noqa: F401
+from . import batch, build, capi, flo, shard  # noqa: F401
 from .capi import Context, FaldoiError, Tvl1Batch, default_params  # noqa: F401

@@ -1,0 +1,153 @@
+"""Batch mode: many independent image pairs sharded over the GPUs of one node (BASELINE configs[3]).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        faldoi-ipol_amd/batch.py jobs.txt [-w 5] [-max_inner 400] [-tol_stop 1]
+
+jobs.txt: one job per line, `I0.png I1.png in_flow.flo|zero out.flo` (what one `global_faldoi` call
+takes, 2-line list-file semantics).  All pairs must have one size.
+
+Data path: rank 0 decodes the inputs and SCATTERS them over RCCL
+(uint8 frames + fp32 initial flows, one message per rank), every rank prepares and solves its
+shard in one batched launch sequence on its own GPU, flows are GATHERED to rank 0, which writes the
+.flo files.  No collective runs during a solve; pairs never talk to each other.
+The collectives go through torch.distributed ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+"""
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def parse_jobs(path):
+    jobs = []
+    with open(path) as f:
+        for ln, line in enumerate(f, 1):
+            parts = line.split()
+            if not parts or parts[0].startswith("#"):
+                continue
+            if len(parts) != 4:
+                raise ValueError("%s:%d: expected `I0 I1 in_flow|zero out.flo`" % (path, ln))
+            jobs.append(tuple(parts))
+    return jobs
+
+
+def shard_sizes(njobs, world):
+    """Round-robin assignment (shard.assign_pairs) expressed as per-rank job index lists."""
+    return [list(range(r, njobs, world)) for r in range(world)]
+
+
+def scatter_inputs(dist, torch, device, rank, world, frames, flows, shape):
+    """frames: (njobs, 2, 3, h, w) uint8 on rank 0 (None elsewhere); flows: (njobs, 2, h, w) float32.
+    Returns this rank's (frames_shard, flows_shard) as numpy arrays."""
+    njobs, h, w = shape
+    idx = shard_sizes(njobs, world)
+    cap = max(len(i) for i in idx)                       # equal-size messages: pad the short shards
+    my_fr = torch.empty((cap, 2, 3, h, w), dtype=torch.uint8, device=device)
+    my_fl = torch.empty((cap, 2, h, w), dtype=torch.float32, device=device)
+    if rank == 0:
+        fr_list, fl_list = [], []
+        for r in range(world):
+            pad = cap - len(idx[r])
+            sel = idx[r] + [idx[r][-1] if idx[r] else 0] * pad
+            fr_list.append(torch.from_numpy(np.ascontiguousarray(frames[sel])).to(device))
+            fl_list.append(torch.from_numpy(np.ascontiguousarray(flows[sel])).to(device))
+    else:
+        fr_list = fl_list = None
+    dist.scatter(my_fr, fr_list, src=0)
+    dist.scatter(my_fl, fl_list, src=0)
+    n_mine = len(idx[rank])
+    return my_fr[:n_mine].cpu().numpy(), my_fl[:n_mine].cpu().numpy()
+
+
+def gather_flows(dist, torch, device, rank, world, flows_mine, shape):
+    """Inverse of scatter_inputs for the results: returns (njobs, 2, h, w) on rank 0, None elsewhere."""
+    njobs, h, w = shape
+    idx = shard_sizes(njobs, world)
+    cap = max(len(i) for i in idx)
+    buf = torch.zeros((cap, 2, h, w), dtype=torch.float32, device=device)
+    if len(flows_mine):
+        buf[:len(flows_mine)] = torch.from_numpy(np.ascontiguousarray(flows_mine)).to(device)
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    res = np.empty((njobs, 2, h, w), np.float32)
+    for r in range(world):
+        for k, j in enumerate(idx[r]):
+            res[j] = out[r][k].cpu().numpy()
+    return res
+
+
+def solve_shard_gpu(frames, flows, local_rank, **params):
+    """frames (n,2,3,h,w) uint8, flows (n,2,h,w) -> refined flows (n,2,h,w) + per-pair iteration counts."""
+    import faldoi_ipol_amd as F
+    n = len(frames)
+    if n == 0:
+        return np.empty((0,) + flows.shape[1:], np.float32), []
+    h, w = frames.shape[-2:]
+    ctx = F.Context(local_rank)
+    b = F.Tvl1Batch(ctx, n, w, h)
+    for i in range(n):
+        b.upload_images(i, frames[i, 0].astype(np.float32), frames[i, 1].astype(np.float32), flows[i])
+    iters, errs, ms, nl = b.solve(**params)
+    out = np.stack([b.download(i) for i in range(n)])
+    b.close()
+    ctx.close()
+    return out, [list(map(int, it)) for it in iters]
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    sys.path.insert(0, os.path.dirname(_HERE))
+    import torch
+    import torch.distributed as dist
+    import faldoi_ipol_amd as F
+
+    def opt(name, default):
+        if "-" + name in argv:
+            i = argv.index("-" + name)
+            v = argv[i + 1]
+            del argv[i:i + 2]
+            return v
+        return default
+
+    params = dict(warps=int(opt("w", 5)), max_inner=int(opt("max_inner", 400)), tol_stop=int(opt("tol_stop", 1)))
+    if len(argv) != 1:
+        raise SystemExit(__doc__)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("nccl", device_id=device)
+
+    meta = [None]
+    frames = flows = None
+    if rank == 0:
+        from PIL import Image
+        jobs = parse_jobs(argv[0])
+        fr = [[np.asarray(Image.open(p).convert("RGB")).transpose(2, 0, 1) for p in job[:2]] for job in jobs]
+        frames = np.ascontiguousarray(np.array(fr, dtype=np.uint8))
+        h, w = frames.shape[-2:]
+        flows = np.stack([np.zeros((2, h, w), np.float32) if job[2] == "zero" else F.flo.read_flo(job[2])
+                          for job in jobs])
+        meta = [(len(jobs), h, w, [job[3] for job in jobs])]
+    dist.broadcast_object_list(meta, src=0)                     # the job table
+    njobs, h, w, outs = meta[0]
+    my_fr, my_fl = scatter_inputs(dist, torch, device, rank, world, frames, flows, (njobs, h, w))
+    res, iters = solve_shard_gpu(my_fr, my_fl, local_rank, **params)
+    allres = gather_flows(dist, torch, device, rank, world, res, (njobs, h, w))
+    if rank == 0:
+        for j, path in enumerate(outs):
+            F.flo.write_flo(path, allres[j])
+        print("batch: %d pairs on %d GPU(s) written" % (njobs, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

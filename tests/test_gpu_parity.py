@@ -251,3 +251,31 @@ def test_global_faldoi_cli_reproduces_the_reference_flo(ctx, tmp_path):
     assert hashlib.sha256(out.read_bytes()).hexdigest().startswith(case["flo_sha256_prefix"])
     lines = [l for l in r.stderr.splitlines() if l.startswith("Warping:")]
     assert [int(l.split("Iter:")[1].split()[0]) for l in lines] == case["iters"]
+
+
+def test_batch_driver_over_rccl_single_rank(oracle, tmp_path):
+    # batch.py end to end under torch.distributed.run with the nccl (= RCCL) backend, 1 rank on the
+    # one GPU this box has: PNG decode -> scatter -> device preprocessing + batched solve -> gather -> .flo
+    import subprocess
+    import sys
+    from PIL import Image
+    crops = [(400, 150, 160, 96), (100, 40, 160, 96), (700, 300, 160, 96)]
+    lines = []
+    for i, c in enumerate(crops):
+        i0, i1 = sintel_pair(c)
+        for k, im in enumerate((i0, i1)):
+            Image.fromarray(im.transpose(1, 2, 0).astype(np.uint8), "RGB").save(tmp_path / ("p%d_%d.png" % (i, k)))
+        lines.append("%s %s zero %s" % (tmp_path / ("p%d_0.png" % i), tmp_path / ("p%d_1.png" % i), tmp_path / ("o%d.flo" % i)))
+    (tmp_path / "jobs.txt").write_text("\n".join(lines) + "\n")
+    root = GOLDEN.rsplit("/tests/", 1)[0]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", root + "/faldoi-ipol_amd/batch.py",
+                        str(tmp_path / "jobs.txt"), "-w", "2", "-max_inner", "40"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i, c in enumerate(crops):
+        i0, i1 = sintel_pair(c)
+        i0n, i1n = oracle.preprocess_global(i0, i1)
+        ou, _, _, _ = oracle.tvl1_global(i0n, i1n, np.zeros((2, 96, 160), np.float32), warps=2, max_inner=40)
+        got = F.flo.read_flo(str(tmp_path / ("o%d.flo" % i)))
+        assert bits_equal(got, ou), i

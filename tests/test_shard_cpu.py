@@ -45,3 +45,52 @@ def test_reduce_timing_gloo_world2():
     for rank, t, u, mine in res:
         assert t == 2.0 and u == 500.0          # MAX of seconds, SUM of units on every rank
     assert res[0][3] == [0, 2, 4] and res[1][3] == [1, 3]
+
+
+def _batch_worker(rank, world, port, q):
+    import numpy as np
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import faldoi_ipol_amd as F2
+    njobs, h, w = 5, 6, 8
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, (njobs, 2, 3, h, w), dtype=np.uint8) if rank == 0 else None
+    flows = rng.standard_normal((njobs, 2, h, w)).astype(np.float32) if rank == 0 else None
+    dev = torch.device("cpu")
+    fr, fl = F2.batch.scatter_inputs(dist, torch, dev, rank, world, frames, flows, (njobs, h, w))
+    # stand-in for the GPU solve (not available in CI): a deterministic function of the inputs
+    res = fl + fr[:, 0, 0].astype(np.float32).mean(axis=(1, 2))[:, None, None, None]
+    allres = F2.batch.gather_flows(dist, torch, dev, rank, world, res, (njobs, h, w))
+    if rank == 0:
+        want = flows + frames[:, 0, 0].astype(np.float32).mean(axis=(1, 2))[:, None, None, None]
+        q.put(bool(np.array_equal(allres, want)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_scatter_gather_gloo_world2():
+    """The RCCL data path of batch.py (scatter inputs, gather flows) with gloo, 2 ranks, 5 jobs:
+    ragged shards (3 + 2) must come back in job order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_batch_job_file_parsing(tmp_path):
+    f = tmp_path / "jobs.txt"
+    f.write_text("# comment\na.png b.png zero o1.flo\n\nc.png d.png in.flo o2.flo\n")
+    assert F.batch.parse_jobs(str(f)) == [("a.png", "b.png", "zero", "o1.flo"), ("c.png", "d.png", "in.flo", "o2.flo")]
+    f.write_text("a.png b.png\n")
+    with pytest.raises(ValueError):
+        F.batch.parse_jobs(str(f))
+    assert F.batch.shard_sizes(5, 2) == [[0, 2, 4], [1, 3]]
