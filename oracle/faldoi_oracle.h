@@ -72,6 +72,13 @@ void orc_tvl1_warp_constants(const float *I0, const float *I1, const float *I1x,
                              const float *u1, const float *u2,
                              float *I1wx, float *I1wy, float *grad, float *rho_c, int nx, int ny);
 
+/* ---- NLTV-CSAD global solver (faldoi_oracle_nltv.c; src/global_faldoi.cpp:891-1174,1332-1374,1642-1808) ---- */
+void orc_image_to_lab(const float *rgb_planar, int size, float *lab_planar);
+void orc_nltv_weights(const float *lab, int pd, int w, int h, float *wts /*[24][n]*/, float *wt /*[n]*/);
+void orc_nltvcsad_global(const float *I0, const float *I1, const float *lab, int pd,
+                         float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
+                         float *u1, float *u2);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

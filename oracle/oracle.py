@@ -17,8 +17,8 @@ _I = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 def build(force=False):
     """Compile liboracle.so (and _ref when the reference sources are present)."""
     so = os.path.join(_HERE, "liboracle.so")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(
-            os.path.join(_HERE, "faldoi_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("faldoi_oracle.c", "faldoi_oracle_nltv.c", "faldoi_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -76,6 +76,10 @@ def lib():
         L.orc_tvl1_iteration.argtypes = [_F] * 12 + [C.c_float] * 3 + [C.c_int] * 2
         L.orc_tvl1_iteration.restype = C.c_float
         L.orc_tvl1_warp_constants.argtypes = [_F] * 10 + [C.c_int] * 2
+        L.orc_image_to_lab.argtypes = [_F, C.c_int, _F]
+        L.orc_nltv_weights.argtypes = [_F, C.c_int, C.c_int, C.c_int, _F, _F]
+        L.orc_nltvcsad_global.argtypes = [_F, _F, _F, C.c_int, C.c_float, C.c_float, C.c_float,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads(cpu_share())      # libgomp may already be loaded (torch) with its own default
@@ -139,3 +143,20 @@ def tvl1_global(i0n, i1n, u0, lam=40.0, theta=0.3, tau=0.125, tol=0.01, warps=5,
                           lam, theta, tau, tol, w, h, warps, max_inner, int(bool(tol_stop)),
                           iters, errs)
     return u, iters, errs, xi
+
+
+def image_to_lab(rgb):
+    rgb = f32(rgb)
+    out = np.empty_like(rgb)
+    lib().orc_image_to_lab(rgb, rgb.shape[1] * rgb.shape[2], out)
+    return out
+
+
+def nltvcsad_global(i0n, i1n, lab, u0, lam=0.85, theta=0.3, tau=0.1, warps=1, max_inner=400):
+    """Reference parameter overrides for -m 6: src/global_faldoi.cpp:2138-2140."""
+    h, w = i0n.shape
+    u = f32(u0).copy()
+    lab = f32(lab)
+    lib().orc_nltvcsad_global(f32(i0n), f32(i1n), lab, lab.shape[0], lam, theta, tau, w, h, warps, max_inner,
+                              u[0], u[1])
+    return u
