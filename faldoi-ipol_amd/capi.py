@@ -24,6 +24,7 @@ EXPORTS = [
     "faldoi_tvl1_batch_last_timing", "faldoi_centered_gradient", "faldoi_forward_gradient",
     "faldoi_divergence", "faldoi_bicubic_warp", "faldoi_selftest_division",
     "faldoi_preprocess_global", "faldoi_tvl1_batch_upload_images",
+    "faldoi_nltvcsad_default_params", "faldoi_nltvcsad_global", "faldoi_image_to_lab",
 ]
 
 
@@ -31,6 +32,11 @@ class Tvl1Params(C.Structure):
     _fields_ = [("lambda_", C.c_float), ("theta", C.c_float), ("tau", C.c_float), ("tol", C.c_float),
                 ("warps", C.c_int), ("max_inner", C.c_int), ("tol_stop", C.c_int), ("chunk", C.c_int),
                 ("verbose", C.c_int)]
+
+
+class NltvCsadParams(C.Structure):
+    _fields_ = [("lambda_", C.c_float), ("theta", C.c_float), ("tau", C.c_float), ("warps", C.c_int),
+                ("max_inner", C.c_int), ("verbose", C.c_int)]
 
 
 class Tvl1Stats(C.Structure):
@@ -90,6 +96,11 @@ def lib():
     L.faldoi_bicubic_warp.argtypes = [vp, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int]
     L.faldoi_preprocess_global.argtypes = [vp, _F, _F, vp, C.c_int, C.c_int, C.c_int, _F, _F]
     L.faldoi_tvl1_batch_upload_images.argtypes = [vp, C.c_int, _F, _F, vp, C.c_int, _F, vp]
+    L.faldoi_nltvcsad_default_params.argtypes = [C.POINTER(NltvCsadParams)]
+    L.faldoi_nltvcsad_default_params.restype = None
+    L.faldoi_nltvcsad_global.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.POINTER(NltvCsadParams), _F,
+                                         C.POINTER(C.c_double)]
+    L.faldoi_image_to_lab.argtypes = [_F, C.c_int, C.c_int, _F]
     L.faldoi_selftest_division.argtypes = [vp, C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
@@ -179,6 +190,19 @@ class Context:
         _check(lib().faldoi_preprocess_global(self._h, i0, i1, _ptr(im1), w, h, pd, o0, o1))
         return o0, o1
 
+    def nltvcsad_global(self, i0n, i1n, lab, u0, **params):
+        """Mirror of nltvcsad_PD.  Returns (u, device ms)."""
+        i0n, i1n, lab = _f32(i0n), _f32(i1n), _f32(lab)
+        h, w = i0n.shape
+        u = _f32(u0).copy()
+        p = NltvCsadParams()
+        lib().faldoi_nltvcsad_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, "lambda_" if k in ("lambda", "lam") else k, v)
+        ms = C.c_double(0)
+        _check(lib().faldoi_nltvcsad_global(self._h, i0n, i1n, lab, lab.shape[0], w, h, C.byref(p), u, C.byref(ms)))
+        return u, ms.value
+
     def selftest_division(self, count=1 << 28, seed=12345):
         bad = C.c_ulonglong(0)
         _check(lib().faldoi_selftest_division(self._h, int(seed), int(count), C.byref(bad)))
@@ -254,3 +278,11 @@ class Tvl1Batch:
         xi = np.empty((4, self.h, self.w), np.float32) if want_xi else None
         _check(lib().faldoi_tvl1_batch_download(self._h, int(pair), u, _ptr(xi)))
         return (u, xi) if want_xi else u
+
+
+def image_to_lab(rgb):
+    """(3,h,w) planar RGB 0..255 -> planar Lab (host side of the library, libm)."""
+    rgb = _f32(rgb)
+    out = np.empty_like(rgb)
+    _check(lib().faldoi_image_to_lab(rgb, rgb.shape[2], rgb.shape[1], out))
+    return out

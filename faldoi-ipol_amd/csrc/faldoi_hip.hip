@@ -6,6 +6,7 @@
 #include "faldoi_hip.h"
 #include "tvl1_kernels.hpp"
 #include "preprocess_kernels.hpp"
+#include "nltv_kernels.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -15,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace faldoi;
@@ -40,6 +42,13 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 // ------------------------------------------------------------------------------------------ types
+namespace {
+struct DevBuf {
+    float *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
 struct faldoi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -679,6 +688,150 @@ extern "C" int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, c
     return FALDOI_OK;
 }
 
+// ------------------------------------------------------------------------------------------ NLTV-CSAD
+// Host-side tables.  They involve pow/exp/hypot, whose last bit is a property of the C library; to
+// stay bit-identical with the reference they are evaluated here with the same libm calls the C++
+// reference resolves to (pow in double, exp of a float argument = expf, hypot in double, sqrtf)
+// and uploaded.  They are computed once per solve; every iteration runs on the device.
+extern "C" void faldoi_nltvcsad_default_params(faldoi_nltvcsad_params *p)
+{
+    if (!p) return;
+    p->lambda = 0.85f;      // src/global_faldoi.cpp:2138-2140: main overrides the -p file for -m 6/7
+    p->theta = 0.3f;
+    p->tau = 0.1f;
+    p->warps = FALDOI_DEFAULT_WARPS_GLOBAL;
+    p->max_inner = FALDOI_DEFAULT_MAX_INNER;
+    p->verbose = 0;
+}
+
+static inline float sqf(float f) { return f * f; }      // aux_pow2, src/global_faldoi.cpp:904
+
+// src/global_faldoi.cpp:906-932
+extern "C" int faldoi_image_to_lab(const float *in, int nx, int ny, float *out)
+{
+    if (!in || !out || nx < 1 || ny < 1) return fail(FALDOI_ERR_INVALID, "bad argument");
+    const int size = nx * ny;
+    const float T = 0.008856f;
+    const float color_attenuation = 1.5f;
+    for (int i = 0; i < size; i++) {
+        const float r = in[i] / 255.f, g = in[i + size] / 255.f, b = in[i + 2 * size] / 255.f;
+        float X = (float)(0.412453 * r + 0.357580 * g + 0.180423 * b);
+        float Y = (float)(0.212671 * r + 0.715160 * g + 0.072169 * b);
+        float Z = (float)(0.019334 * r + 0.119193 * g + 0.950227 * b);
+        X = (float)(X / 0.950456);
+        Z = (float)(Z / 1.088754);
+        const float Y3 = (float)std::pow((double)Y, 1. / 3);
+        const float fX = (float)(X > T ? std::pow((double)X, 1. / 3) : 7.787 * X + 16 / 116.);
+        const float fY = (float)(Y > T ? (double)Y3 : 7.787 * Y + 16 / 116.);
+        const float fZ = (float)(Z > T ? std::pow((double)Z, 1. / 3) : 7.787 * Z + 16 / 116.);
+        const float L = (float)(Y > T ? 116 * Y3 - 16.0 : 903.3 * Y);
+        const float A = 500 * (fX - fY);
+        const float B = 200 * (fY - fZ);
+        const float inner = (float)(sqf(L / 100) - 0.6);            // aux_pow2 takes a float
+        const float correct_lab = expf(-color_attenuation * sqf(inner));
+        out[i] = L;
+        out[i + size] = A * correct_lab;
+        out[i + 2 * size] = B * correct_lab;
+    }
+    return FALDOI_OK;
+}
+
+// Weights of the 24 dual slots and their sum, src/global_faldoi.cpp:935-1054.  wts: [24][n], wt: [n].
+static void nltv_weights_rows(const float *a, int pd, int w, int h, int y0, int y1, float *wts, float *wt)
+{
+    const size_t n = (size_t)w * h;
+    for (int j = y0; j < y1; j++)
+        for (int i = 0; i < w; i++) {
+            const size_t pos = (size_t)j * w + i;
+            int it = 0;
+            float ne = 0.0f;
+            for (int k = -kNlR; k <= kNlR; k++)
+                for (int l = -kNlR; l <= kNlR; l++) {
+                    if (k == 0 && l == 0) continue;
+                    float wp = 0.0f;
+                    if (i + l >= 0 && i + l < w && j + k >= 0 && j + k < h) {
+                        float difI = 0.0f;
+                        for (int m = 0; m < pd; m++) {
+                            const float aux = a[n * m + pos] - a[n * m + (size_t)(j + k) * w + (i + l)];
+                            difI += aux * aux;
+                        }
+                        difI = sqrtf(difI);
+                        const float wc = expf(-difI / 5.0f);                          // MAX_INTENSITY
+                        const float difS = (float)hypot((double)l, (double)k);
+                        const float ws = expf(-difS / 2.0f);                          // MAX_BETA
+                        wp = sqrtf(wc * ws);
+                        ne += wp;
+                    }
+                    wts[(size_t)it * n + pos] = wp;
+                    it++;
+                }
+            wt[pos] = ne;
+        }
+}
+
+extern "C" int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
+                                      int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
+{
+    if (!ctx || !I0 || !I1 || !a || !prm || !u) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    if (pd < 1 || pd > 4) return fail(FALDOI_ERR_INVALID, "pd=%d unsupported", pd);
+    if (nx < 2 || ny < 2 || (long)nx * ny > (1L << 26)) return fail(FALDOI_ERR_INVALID, "image size %dx%d unsupported", nx, ny);
+    if (!(prm->lambda > 0) || !(prm->theta > 0) || !(prm->tau > 0) || prm->warps < 1 || prm->max_inner < 1)
+        return fail(FALDOI_ERR_INVALID, "bad NLTV-CSAD parameters");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t n = (size_t)nx * ny, nb = n * sizeof(float);
+    const size_t pe = ((n + 63) / 64) * 64;
+
+    // host tables (threads over row bands)
+    std::vector<float> wts((size_t)kNlSlots * n), wt(n);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+        if ((unsigned)ny < nt) nt = (unsigned)ny;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back(nltv_weights_rows, a, pd, nx, ny, (int)((long)ny * t / nt), (int)((long)ny * (t + 1) / nt),
+                            wts.data(), wt.data());
+        for (auto &t : th) t.join();
+    }
+
+    DevBuf buf;
+    HIP_TRY(hipMalloc((void **)&buf.p, sizeof(float) * pe * N_COUNT));
+    float *base = buf.p;
+    HIP_TRY(hipMemsetAsync(base, 0, sizeof(float) * pe * N_COUNT, s));          // duals and b start at 0 (:1031,:1347)
+    HIP_TRY(hipMemcpyAsync(base + N_I0 * pe, I0, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + N_I1 * pe, I1, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + N_U1 * pe, u, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + N_U2 * pe, u + n, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + N_WT * pe, wt.data(), nb, hipMemcpyHostToDevice, s));
+    for (int k = 0; k < kNlSlots; ++k)
+        HIP_TRY(hipMemcpyAsync(base + (size_t)(N_W + k) * pe, wts.data() + (size_t)k * n, nb, hipMemcpyHostToDevice, s));
+
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const float l_t = prm->lambda * prm->theta;                                 // :1659
+    HIP_TRY(hipEventRecord(ctx->ev0, s));
+    hipLaunchKernelGGL(centered_gradient_kernel, grid, block, 0, s, base + N_I1 * pe, base + N_I1X * pe, base + N_I1Y * pe,
+                       nx, ny, (size_t)0, (size_t)0, 1);                        // :1690
+    for (int w = 0; w < prm->warps; ++w) {
+        hipLaunchKernelGGL(nl_warp_kernel, grid, block, 0, s, base, pe, nx, ny);
+        hipLaunchKernelGGL(nl_csad_terms_kernel, grid, block, 0, s, base, pe, nx, ny);
+        for (int it = 0; it < prm->max_inner; ++it) {                           // :1729, no tolerance test
+            hipLaunchKernelGGL(nl_dual_kernel, grid, block, 0, s, base, pe, nx, ny, prm->tau);
+            hipLaunchKernelGGL(nl_primal_kernel, grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ctx->ev1, s));
+    HIP_TRY(hipMemcpyAsync(u, base + N_U1 * pe, nb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(u + n, base + N_U2 * pe, nb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (solve_ms) *solve_ms = ms;
+    if (prm->verbose) fprintf(stderr, "NLTV-CSAD: %d warps x %d iterations, %.3f ms on the device\n", prm->warps, prm->max_inner, ms);
+    return FALDOI_OK;
+}
+
 // ------------------------------------------------------------------------------------------ self-test
 extern "C" int faldoi_selftest_division(faldoi_ctx *ctx, unsigned seed, unsigned long long count,
                                         unsigned long long *mismatches)
@@ -719,12 +872,6 @@ extern "C" int faldoi_selftest_division(faldoi_ctx *ctx, unsigned seed, unsigned
 }
 
 // ------------------------------------------------------------------------------------------ primitives
-namespace {
-struct DevBuf {
-    float *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
-}  // namespace
 
 static int prim_check(faldoi_ctx *ctx, int nx, int ny)
 {

@@ -148,6 +148,28 @@ int faldoi_preprocess_global(faldoi_ctx *ctx, const float *i0, const float *i1, 
 int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
                                     const float *im1, int pd, const float *u, const float *xi);
 
+/* ---------------------------------------------------------------- NLTV-CSAD functional (method 6)
+ * Replaces  void nltvcsad_PD(const float *I0, float *I1, float *a, int pd, lambda, theta, tau, w, h,
+ *                            warps, verbose, float *u1, float *u2)      src/global_faldoi.cpp:1642-1808
+ * I0, I1: preprocessed gray planes; a: Lab image of the RAW first frame (pd planes, what
+ * image_to_lab returns, :2042-2047); u: 2 contiguous planes, in/out.  400 inner iterations per warp
+ * without a tolerance test, as in the reference (:1729); max_inner makes that bound explicit.
+ * The neighbour weights (exp/hypot/sqrt of Lab differences) are evaluated on the host with the
+ * C library for bit parity and uploaded; all warps and iterations run on the device. */
+typedef struct faldoi_nltvcsad_params {
+    float lambda;      /* 0.85: main overrides the parameter file for this method (:2138-2140) */
+    float theta;       /* 0.3  */
+    float tau;         /* 0.1  */
+    int warps;         /* -w, default 5 */
+    int max_inner;     /* reference: MAX_ITERATIONS_GLOBAL = 400 */
+    int verbose;
+} faldoi_nltvcsad_params;
+void faldoi_nltvcsad_default_params(faldoi_nltvcsad_params *p);
+int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd,
+                           int nx, int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms);
+/* src/global_faldoi.cpp:906-932 image_to_lab: planar R,G,B (0..255) -> planar L,a*,b* (host, libm). */
+int faldoi_image_to_lab(const float *rgb, int nx, int ny, float *lab);
+
 /* ---------------------------------------------------------------- self-test
  * The kernels replace the IEEE fp32 divide on two call sites by an fp64-assisted sequence that
  * is proven to return the same bits (csrc/faldoi_device.hpp).  This entry point checks the claim

@@ -68,3 +68,13 @@ def test_flo_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.flo").write_bytes(b"PIEHxx")
         F.flo.read_flo(str(tmp_path / "bad.flo"))
+
+
+def test_image_to_lab_host_function_matches_the_oracle(oracle):
+    # host-side table code of the library (libm): same bits as the checker's restatement
+    rng = np.random.default_rng(3)
+    rgb = np.floor(rng.random((3, 19, 23)) * 256).astype(np.float32)
+    rgb[:, 0, :3] = [[0, 255, 1], [0, 255, 2], [0, 255, 3]]
+    a = F.capi.image_to_lab(rgb)
+    b = oracle.image_to_lab(rgb)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

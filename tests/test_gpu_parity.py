@@ -279,3 +279,35 @@ def test_batch_driver_over_rccl_single_rank(oracle, tmp_path):
         ou, _, _, _ = oracle.tvl1_global(i0n, i1n, np.zeros((2, 96, 160), np.float32), warps=2, max_inner=40)
         got = F.flo.read_flo(str(tmp_path / ("o%d.flo" % i)))
         assert bits_equal(got, ou), i
+
+
+# ------------------------------------------------------------------ NLTV-CSAD (BASELINE configs[4])
+def test_nltvcsad_crop_known_answer(ctx, oracle):
+    case = known_answers()["sintel_clean_easy_f2_f3_crop_400_150_128x96_nltvcsad_w1"]
+    i0, i1 = sintel_pair((case["x0"], case["y0"], case["w"], case["h"]))
+    i0n, i1n = ctx.preprocess_global(i0, i1)
+    lab = F.capi.image_to_lab(i0)
+    u, ms = ctx.nltvcsad_global(i0n, i1n, lab, np.zeros((2, case["h"], case["w"]), np.float32),
+                                warps=1, max_inner=case["inner"])
+    ou = oracle.nltvcsad_global(oracle.preprocess_global(i0, i1)[0], oracle.preprocess_global(i0, i1)[1],
+                                oracle.image_to_lab(i0), np.zeros((2, case["h"], case["w"]), np.float32))
+    epe = float(F.flo.epe(u, ou).mean())
+    assert epe <= EPE_GATE, epe
+    assert bits_equal(u, ou), mismatch_report(u, ou)
+    assert flo_sha256(u).startswith(case["flo_sha256_prefix"])      # the compiled reference's own output
+
+
+@pytest.mark.parametrize("w,h,warps,inner", [(40, 30, 2, 25), (97, 64, 1, 40), (7, 9, 2, 10)])
+def test_nltvcsad_bit_exact_small(ctx, oracle, w, h, warps, inner):
+    rng = np.random.default_rng(w * h)
+    i0n, i1n, gt = synthetic_pair(max(w, 16), max(h, 16), seed=w)
+    i0n, i1n, gt = i0n[:h, :w].copy(), i1n[:h, :w].copy(), gt[:, :h, :w].copy()
+    rgb = np.floor(rng.random((3, h, w)) * 256).astype(np.float32)
+    rgb[:, : h // 2] = np.floor(i0n[: h // 2] * 255)[None]          # half structured, half noise
+    lab = F.capi.image_to_lab(rgb)
+    assert bits_equal(lab, oracle.image_to_lab(rgb))
+    u0 = (gt + rng.standard_normal(gt.shape) * 0.3).astype(np.float32)
+    u, ms = ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=warps, max_inner=inner)
+    ou = oracle.nltvcsad_global(i0n, i1n, lab, u0, warps=warps, max_inner=inner)
+    assert float(F.flo.epe(u, ou).mean()) <= EPE_GATE
+    assert bits_equal(u, ou), mismatch_report(u, ou)
