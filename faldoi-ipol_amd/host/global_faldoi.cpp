@@ -10,7 +10,8 @@
 // ims.txt: one path per line: I0, I1 [, I-1, I2].  As in the reference, I-1 is only used when
 // the file has four lines, otherwise I1 takes its place in the normalisation (:1933-1937).
 // Methods: 0 (TV-l2 coupled) and 1 (its weighted id, which the reference's global step maps to the
-// same solver, :2132).  Other functionals are not part of this build and are refused loudly.
+// same solver, :2132); 6 (NLTV-CSAD) and 7 (its weighted id, same solver, :2137).  The other
+// functionals are not part of this build and are refused loudly.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -48,8 +49,9 @@ int main(int argc, char *argv[])
         const int chunk = std::stoi(pick_option(args, "chunk", "0"));
         const int gpu = std::stoi(pick_option(args, "gpu", "0"));
         if (args.size() != 4) return usage(args.size());
-        if (method != 0 && method != 1) {
-            fprintf(stderr, "ERROR: method %d is not available in this build (TV-l2 coupled, -m 0/1, only)\n", method);
+        const bool tvl1 = method == 0 || method == 1, nltvcsad = method == 6 || method == 7;
+        if (!tvl1 && !nltvcsad) {
+            fprintf(stderr, "ERROR: method %d is not available in this build (TV-l2 coupled -m 0/1, NLTV-CSAD -m 6/7)\n", method);
             return 2;
         }
 
@@ -83,6 +85,27 @@ int main(int argc, char *argv[])
         faldoi_tvl1_default_params(&prm);
         prm.lambda = ep.lambda; prm.theta = ep.theta; prm.tau = ep.tau; prm.tol = ep.tol;
         prm.warps = nwarps; prm.max_inner = max_inner; prm.tol_stop = tol_stop; prm.chunk = chunk; prm.verbose = verbose;
+
+        if (nltvcsad) {                                   // src/global_faldoi.cpp:2042-2047,2137-2143
+            if (pd != 3) { fprintf(stderr, "ERROR: NLTV-CSAD needs colour images (Lab weights)\n"); return EXIT_FAILURE; }
+            faldoi_ctx *c = nullptr;
+            if (faldoi_ctx_create(gpu, &c)) { fprintf(stderr, "ERROR: no usable GPU: %s\n", faldoi_last_error()); return 3; }
+            const size_t n = (size_t)i0.w * i0.h;
+            printf("W:%d H:%d Pd:%d\n", i0.w, i0.h, i0.pd);        // :2044
+            std::vector<float> lab(3 * n), i0n(n), i1n(n), u(flow.data);
+            int rc = faldoi_image_to_lab(i0.data.data(), i0.w, i0.h, lab.data());
+            if (!rc) rc = faldoi_preprocess_global(c, i0.data.data(), i1.data.data(), have_im1 ? im1.data.data() : nullptr,
+                                                   i0.w, i0.h, pd, i0n.data(), i1n.data());
+            faldoi_nltvcsad_params np;
+            faldoi_nltvcsad_default_params(&np);          // lambda/theta/tau are forced for this method (:2138-2140)
+            np.warps = nwarps; np.max_inner = max_inner; np.verbose = verbose;
+            if (!rc) rc = faldoi_nltvcsad_global(c, i0n.data(), i1n.data(), lab.data(), 3, i0.w, i0.h, &np, u.data(), nullptr);
+            if (rc) fprintf(stderr, "ERROR: %s\n", faldoi_last_error());
+            faldoi_ctx_destroy(c);
+            if (rc) return 3;
+            write_flo(args[3], u.data(), i0.w, i0.h);
+            return EXIT_SUCCESS;
+        }
 
         faldoi_ctx *ctx = nullptr;
         faldoi_tvl1_batch *batch = nullptr;

@@ -311,3 +311,22 @@ def test_nltvcsad_bit_exact_small(ctx, oracle, w, h, warps, inner):
     ou = oracle.nltvcsad_global(i0n, i1n, lab, u0, warps=warps, max_inner=inner)
     assert float(F.flo.epe(u, ou).mean()) <= EPE_GATE
     assert bits_equal(u, ou), mismatch_report(u, ou)
+
+
+def test_global_faldoi_cli_method6_reproduces_the_reference_flo(tmp_path):
+    # `global_faldoi ims.txt zero.flo out.flo -m 6 -w 1` on the 128x96 crop: byte-identical to the
+    # compiled reference's output
+    import hashlib
+    import subprocess
+    from PIL import Image
+    case = known_answers()["sintel_clean_easy_f2_f3_crop_400_150_128x96_nltvcsad_w1"]
+    i0, i1 = sintel_pair((case["x0"], case["y0"], case["w"], case["h"]))
+    for k, im in enumerate((i0, i1)):
+        Image.fromarray(im.transpose(1, 2, 0).astype(np.uint8), "RGB").save(tmp_path / ("c%d.png" % k))
+    (tmp_path / "ims.txt").write_text("%s\n%s\n" % (tmp_path / "c0.png", tmp_path / "c1.png"))
+    F.flo.write_flo(str(tmp_path / "zero.flo"), np.zeros((2, case["h"], case["w"]), np.float32))
+    bins = F.build.build_host()
+    r = subprocess.run([bins["global_faldoi"], str(tmp_path / "ims.txt"), str(tmp_path / "zero.flo"),
+                        str(tmp_path / "out.flo"), "-m", "6", "-w", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert hashlib.sha256((tmp_path / "out.flo").read_bytes()).hexdigest().startswith(case["flo_sha256_prefix"])
