@@ -3,6 +3,8 @@
 The .so is git-ignored but travels to the GPU box with the repo snapshot.  hipcc cross-compiles
 gfx950 code objects without a GPU, so this runs in the CPU-only build container too.
 """
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -46,14 +48,32 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """Serialises builds across processes (every rank of a multi-GPU launch imports this package);
+    the output is written to a temporary name and renamed, so a reader never sees a partial file."""
+    fd = os.open(os.path.join(HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
-                                    "-o", SO] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with _build_lock():
+        if not force and not needs_build():          # another process built it while we waited
+            return SO
+        tmp = SO + ".tmp.%d" % os.getpid()
+        cmd = [hipcc()] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+                                        "-o", tmp] + SOURCES
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, SO)
     return SO
 
 
@@ -63,19 +83,22 @@ def build_host(force=False, verbose=False):
     cxx = shutil.which("g++") or "g++"
     hdrs = [os.path.join(HOST, f) for f in ("image_io.hpp", "options.hpp")] + [os.path.join(ROOT, "include", "faldoi_hip.h")]
     out = {}
-    for name, (srcs, needs_lib) in HOST_PROGRAMS.items():
-        exe = os.path.join(BIN, name)
-        out[name] = exe
-        deps = srcs + HOST_COMMON + hdrs + ([SO] if needs_lib else [])
-        if not force and os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
-            continue
-        cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, "-o", exe] + srcs + HOST_COMMON
-        if needs_lib:
-            cmd += ["-L" + HERE, "-lfaldoi_hip", "-Wl,-rpath,$ORIGIN/.."]
-        cmd += ["-lz"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    with _build_lock():
+        for name, (srcs, needs_lib) in HOST_PROGRAMS.items():
+            exe = os.path.join(BIN, name)
+            out[name] = exe
+            deps = srcs + HOST_COMMON + hdrs + ([SO] if needs_lib else [])
+            if not force and os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
+                continue
+            tmp = exe + ".tmp.%d" % os.getpid()
+            cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, "-o", tmp] + srcs + HOST_COMMON
+            if needs_lib:
+                cmd += ["-L" + HERE, "-lfaldoi_hip", "-Wl,-rpath,$ORIGIN/.."]
+            cmd += ["-lz"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, exe)
     return out
 
 

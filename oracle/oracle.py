@@ -17,11 +17,18 @@ _I = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 def build(force=False):
     """Compile liboracle.so (and _ref when the reference sources are present)."""
     so = os.path.join(_HERE, "liboracle.so")
+    import fcntl
     srcs = [os.path.join(_HERE, f) for f in ("faldoi_oracle.c", "faldoi_oracle_nltv.c", "faldoi_oracle.h")]
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/src"):
-        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    fd = os.open(os.path.join(_HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)              # several ranks / xdist workers may get here together
+        if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        if os.path.isdir("/root/reference/src"):
+            subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
     return so
 
 
