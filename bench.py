@@ -25,7 +25,7 @@ BYTES_PER_PX_WARP = 44        # per outer warp (bicubic gathers + constants)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # HBM bytes per launch of tvl1_chunk_kernel from rocprofv3 PMC passes (profiles/): filled in from the
 # committed counter summaries; None until measured for the current kernel.
-TRAFFIC_BYTES_PER_LAUNCH = None
+TRAFFIC_BYTES_PER_LAUNCH = 36303872   # (2*10739 + 13975) KB, profiles/r01_pmc_sq_v5.md (1024x436, k=10)
 
 
 def main():
@@ -136,7 +136,8 @@ def main():
                        "pairs_per_gpu": npairs, "parallelism": "pairs-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "tvl1_chunk_kernel",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH if (npairs == 1 and args.chunk in (0, 10)) else None,
                          "launch_us": round(launch_us, 2), "launch_us_source":
                              "HIP event pair around every launch" if kernel_us else "solve time / launches",
                          "solve_us_per_launch_incl_warp_kernel": round(group_us, 2),
