@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=1)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,6 +145,16 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "inner_iters_per_launch": round(iters_per_launch, 2)},
         }
+        if world == 1 and data_kind != "synthetic" and not args.no_secondary:
+            # BASELINE configs[4] (not the headline): NLTV-CSAD, same pair, 1 warp x 400 iterations
+            lab = F.capi.image_to_lab(load_rgb_planar(f2))
+            i0n, i1n, u0 = pairs[0]
+            ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=20)            # warm-up
+            _, nl_ms = ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=400)
+            out["secondary"] = {"nltvcsad_1024x436_1warp_x_400": {
+                "device_ms": round(nl_ms, 2), "Mpx_iter_per_s": round(W * H * 400 / nl_ms / 1e3, 1),
+                "algorithmic_GBps": round(720.0 * W * H * 400 / (nl_ms * 1e-3) / 1e9, 1),
+                "note": "two streaming launches per iteration, ~720 B/px/iteration (SURVEY 8d, approximate)"}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O            # checker + timed CPU baseline only
             i0n, i1n, u0 = pairs[0]

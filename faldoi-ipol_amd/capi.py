@@ -25,6 +25,7 @@ EXPORTS = [
     "faldoi_divergence", "faldoi_bicubic_warp", "faldoi_selftest_division",
     "faldoi_preprocess_global", "faldoi_tvl1_batch_upload_images",
     "faldoi_nltvcsad_default_params", "faldoi_nltvcsad_global", "faldoi_image_to_lab",
+    "faldoi_nltvl1_default_params", "faldoi_nltvl1_global",
 ]
 
 
@@ -101,6 +102,9 @@ def lib():
     L.faldoi_nltvcsad_global.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.POINTER(NltvCsadParams), _F,
                                          C.POINTER(C.c_double)]
     L.faldoi_image_to_lab.argtypes = [_F, C.c_int, C.c_int, _F]
+    L.faldoi_nltvl1_default_params.argtypes = [C.POINTER(NltvCsadParams)]
+    L.faldoi_nltvl1_default_params.restype = None
+    L.faldoi_nltvl1_global.argtypes = L.faldoi_nltvcsad_global.argtypes
     L.faldoi_selftest_division.argtypes = [vp, C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
@@ -190,18 +194,27 @@ class Context:
         _check(lib().faldoi_preprocess_global(self._h, i0, i1, _ptr(im1), w, h, pd, o0, o1))
         return o0, o1
 
-    def nltvcsad_global(self, i0n, i1n, lab, u0, **params):
-        """Mirror of nltvcsad_PD.  Returns (u, device ms)."""
+    def _nl_global(self, defaults, solve, i0n, i1n, lab, u0, params):
         i0n, i1n, lab = _f32(i0n), _f32(i1n), _f32(lab)
         h, w = i0n.shape
         u = _f32(u0).copy()
         p = NltvCsadParams()
-        lib().faldoi_nltvcsad_default_params(C.byref(p))
+        defaults(C.byref(p))
         for k, v in params.items():
             setattr(p, "lambda_" if k in ("lambda", "lam") else k, v)
         ms = C.c_double(0)
-        _check(lib().faldoi_nltvcsad_global(self._h, i0n, i1n, lab, lab.shape[0], w, h, C.byref(p), u, C.byref(ms)))
+        _check(solve(self._h, i0n, i1n, lab, lab.shape[0], w, h, C.byref(p), u, C.byref(ms)))
         return u, ms.value
+
+    def nltvcsad_global(self, i0n, i1n, lab, u0, **params):
+        """Mirror of nltvcsad_PD.  Returns (u, device ms)."""
+        return self._nl_global(lib().faldoi_nltvcsad_default_params, lib().faldoi_nltvcsad_global,
+                               i0n, i1n, lab, u0, params)
+
+    def nltvl1_global(self, i0n, i1n, lab, u0, **params):
+        """Mirror of nltvl1_PD.  Returns (u, device ms)."""
+        return self._nl_global(lib().faldoi_nltvl1_default_params, lib().faldoi_nltvl1_global,
+                               i0n, i1n, lab, u0, params)
 
     def selftest_division(self, count=1 << 28, seed=12345):
         bad = C.c_ulonglong(0)

@@ -769,8 +769,30 @@ static void nltv_weights_rows(const float *a, int pd, int w, int h, int y0, int 
         }
 }
 
+static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
+                    int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms);
+
 extern "C" int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
                                       int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
+{
+    return nl_solve(false, ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms);
+}
+
+extern "C" void faldoi_nltvl1_default_params(faldoi_nltvcsad_params *p)
+{
+    if (!p) return;
+    faldoi_nltvcsad_default_params(p);
+    p->lambda = 2.0f;      // src/global_faldoi.cpp:2146-2148: main overrides the -p file for -m 2/3
+}
+
+extern "C" int faldoi_nltvl1_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
+                                    int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
+{
+    return nl_solve(true, ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms);
+}
+
+static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
+                    int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
 {
     if (!ctx || !I0 || !I1 || !a || !prm || !u) return fail(FALDOI_ERR_INVALID, "NULL argument");
     if (pd < 1 || pd > 4) return fail(FALDOI_ERR_INVALID, "pd=%d unsupported", pd);
@@ -813,11 +835,14 @@ extern "C" int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const fl
     hipLaunchKernelGGL(centered_gradient_kernel, grid, block, 0, s, base + N_I1 * pe, base + N_I1X * pe, base + N_I1Y * pe,
                        nx, ny, (size_t)0, (size_t)0, 1);                        // :1690
     for (int w = 0; w < prm->warps; ++w) {
-        hipLaunchKernelGGL(nl_warp_kernel, grid, block, 0, s, base, pe, nx, ny);
-        hipLaunchKernelGGL(nl_csad_terms_kernel, grid, block, 0, s, base, pe, nx, ny);
-        for (int it = 0; it < prm->max_inner; ++it) {                           // :1729, no tolerance test
+        hipLaunchKernelGGL(nl_warp_kernel, grid, block, 0, s, base, pe, nx, ny, data_l1 ? 1 : 0);
+        if (!data_l1) hipLaunchKernelGGL(nl_csad_terms_kernel, grid, block, 0, s, base, pe, nx, ny);
+        for (int it = 0; it < prm->max_inner; ++it) {                           // :1729 / :1240, no tolerance test
             hipLaunchKernelGGL(nl_dual_kernel, grid, block, 0, s, base, pe, nx, ny, prm->tau);
-            hipLaunchKernelGGL(nl_primal_kernel, grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);
+            if (data_l1)
+                hipLaunchKernelGGL(nl_primal_kernel<true>, grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);
+            else
+                hipLaunchKernelGGL(nl_primal_kernel<false>, grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -828,7 +853,7 @@ extern "C" int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const fl
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (solve_ms) *solve_ms = ms;
-    if (prm->verbose) fprintf(stderr, "NLTV-CSAD: %d warps x %d iterations, %.3f ms on the device\n", prm->warps, prm->max_inner, ms);
+    if (prm->verbose) fprintf(stderr, "NLTV (%s data term): %d warps x %d iterations, %.3f ms on the device\n", data_l1 ? "L1" : "CSAD", prm->warps, prm->max_inner, ms);
     return FALDOI_OK;
 }
 

@@ -33,7 +33,8 @@ enum NlPlane {
 };
 
 // Per-warp: three bicubic warps (border_out = true), grad = I1wx^2 + I1wy^2, ubar = u (:1694-1725)
-__global__ __launch_bounds__(256) void nl_warp_kernel(float *__restrict__ base, size_t pe, int nx, int ny)
+// data_l1 (NLTV-L1, src/global_faldoi.cpp:1226-1234): the N_I1W plane receives rho_c instead of I1w.
+__global__ __launch_bounds__(256) void nl_warp_kernel(float *__restrict__ base, size_t pe, int nx, int ny, int data_l1)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= nx * ny) return;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void nl_warp_kernel(float *__restrict__ base, 
         wx = bicubic_eval(base + N_I1X * pe, tp, nx);
         wy = bicubic_eval(base + N_I1Y * pe, tp, nx);
     }
-    base[N_I1W * pe + p] = w0;
+    base[N_I1W * pe + p] = data_l1 ? rho_const(w0, wx, wy, u1, u2, base[N_I0 * pe + p]) : w0;
     base[N_I1WX * pe + p] = wx;
     base[N_I1WY * pe + p] = wy;
     base[N_GRAD * pe + p] = grad_sq(wx, wy);
@@ -141,6 +142,8 @@ __device__ __forceinline__ void bitonic_sort64(float (&v)[64])
 // ascending sort of  A = { -(b_s - r) : valid s }  united with  B = { (n-2j)*l_t*sg : j = 0..n }.
 // A is sorted in registers (padding = +inf); B is an arithmetic progression, so the order statistic
 // is  min over i of max(A_sorted[i-1], B_ascending[n+1-i])  -- the classic two-sorted-arrays split.
+// DATA_L1 = true: the data step is TV-L1's thresholding (nltvl1_PD, :1246-1272) on rho_c.
+template <bool DATA_L1>
 __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base, size_t pe, int nx, int ny,
                                                         float l_t, float theta, float tau)
 {
@@ -150,7 +153,10 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
     const float u1k = base[N_U1 * pe + i], u2k = base[N_U2 * pe + i];
     const float grad = base[N_GRAD * pe + i];
     float v1 = u1k, v2 = u2k;                                            // :1735-1736
-    if (!(grad < grad_zero_bound())) {
+    if (DATA_L1) {
+        const float ixw = base[N_I1WX * pe + i], iyw = base[N_I1WY * pe + i];
+        threshold_step(base[N_I1W * pe + i], ixw, iyw, grad, recip_f64(grad), u1k, u2k, l_t, v1, v2);
+    } else if (!(grad < grad_zero_bound())) {
         const float ixw = base[N_I1WX * pe + i], iyw = base[N_I1WY * pe + i];
         const float sg = __builtin_sqrtf(grad);
         const float r = (ixw * u1k + iyw * u2k) / sg;

@@ -10,7 +10,7 @@
 // ims.txt: one path per line: I0, I1 [, I-1, I2].  As in the reference, I-1 is only used when
 // the file has four lines, otherwise I1 takes its place in the normalisation (:1933-1937).
 // Methods: 0 (TV-l2 coupled) and 1 (its weighted id, which the reference's global step maps to the
-// same solver, :2132); 6 (NLTV-CSAD) and 7 (its weighted id, same solver, :2137).  The other
+// same solver, :2132); 2/3 (NLTV-L1, :2145) and 6/7 (NLTV-CSAD, :2137), likewise.  The other
 // functionals are not part of this build and are refused loudly.
 #include <cstdio>
 #include <cstdlib>
@@ -49,9 +49,11 @@ int main(int argc, char *argv[])
         const int chunk = std::stoi(pick_option(args, "chunk", "0"));
         const int gpu = std::stoi(pick_option(args, "gpu", "0"));
         if (args.size() != 4) return usage(args.size());
-        const bool tvl1 = method == 0 || method == 1, nltvcsad = method == 6 || method == 7;
-        if (!tvl1 && !nltvcsad) {
-            fprintf(stderr, "ERROR: method %d is not available in this build (TV-l2 coupled -m 0/1, NLTV-CSAD -m 6/7)\n", method);
+        const bool tvl1 = method == 0 || method == 1, nltvl1 = method == 2 || method == 3;
+        const bool nltvcsad = method == 6 || method == 7;
+        if (!tvl1 && !nltvcsad && !nltvl1) {
+            fprintf(stderr, "ERROR: method %d is not available in this build (TV-l2 coupled -m 0/1, NLTV-L1 -m 2/3, "
+                            "NLTV-CSAD -m 6/7)\n", method);
             return 2;
         }
 
@@ -86,8 +88,8 @@ int main(int argc, char *argv[])
         prm.lambda = ep.lambda; prm.theta = ep.theta; prm.tau = ep.tau; prm.tol = ep.tol;
         prm.warps = nwarps; prm.max_inner = max_inner; prm.tol_stop = tol_stop; prm.chunk = chunk; prm.verbose = verbose;
 
-        if (nltvcsad) {                                   // src/global_faldoi.cpp:2042-2047,2137-2143
-            if (pd != 3) { fprintf(stderr, "ERROR: NLTV-CSAD needs colour images (Lab weights)\n"); return EXIT_FAILURE; }
+        if (nltvcsad || nltvl1) {                         // src/global_faldoi.cpp:2042-2047,2137-2151
+            if (pd != 3) { fprintf(stderr, "ERROR: the NLTV functionals need colour images (Lab weights)\n"); return EXIT_FAILURE; }
             faldoi_ctx *c = nullptr;
             if (faldoi_ctx_create(gpu, &c)) { fprintf(stderr, "ERROR: no usable GPU: %s\n", faldoi_last_error()); return 3; }
             const size_t n = (size_t)i0.w * i0.h;
@@ -96,10 +98,11 @@ int main(int argc, char *argv[])
             int rc = faldoi_image_to_lab(i0.data.data(), i0.w, i0.h, lab.data());
             if (!rc) rc = faldoi_preprocess_global(c, i0.data.data(), i1.data.data(), have_im1 ? im1.data.data() : nullptr,
                                                    i0.w, i0.h, pd, i0n.data(), i1n.data());
-            faldoi_nltvcsad_params np;
-            faldoi_nltvcsad_default_params(&np);          // lambda/theta/tau are forced for this method (:2138-2140)
+            faldoi_nltvcsad_params np;                    // lambda/theta/tau are forced per method (:2138-2148)
+            if (nltvl1) faldoi_nltvl1_default_params(&np); else faldoi_nltvcsad_default_params(&np);
             np.warps = nwarps; np.max_inner = max_inner; np.verbose = verbose;
-            if (!rc) rc = faldoi_nltvcsad_global(c, i0n.data(), i1n.data(), lab.data(), 3, i0.w, i0.h, &np, u.data(), nullptr);
+            if (!rc) rc = nltvl1 ? faldoi_nltvl1_global(c, i0n.data(), i1n.data(), lab.data(), 3, i0.w, i0.h, &np, u.data(), nullptr)
+                                 : faldoi_nltvcsad_global(c, i0n.data(), i1n.data(), lab.data(), 3, i0.w, i0.h, &np, u.data(), nullptr);
             if (rc) fprintf(stderr, "ERROR: %s\n", faldoi_last_error());
             faldoi_ctx_destroy(c);
             if (rc) return 3;

@@ -167,6 +167,12 @@ typedef struct faldoi_nltvcsad_params {
 void faldoi_nltvcsad_default_params(faldoi_nltvcsad_params *p);
 int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd,
                            int nx, int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms);
+/* NLTV-L1 (method 2/3): replaces nltvl1_PD, src/global_faldoi.cpp:1177-1327 -- the same non-local
+ * regulariser with TV-L1's data term.  Same argument meaning as faldoi_nltvcsad_global; the default
+ * parameters are the ones main forces for this method (lambda 2.0, theta 0.3, tau 0.1, :2146-2148). */
+void faldoi_nltvl1_default_params(faldoi_nltvcsad_params *p);
+int faldoi_nltvl1_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd,
+                         int nx, int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms);
 /* src/global_faldoi.cpp:906-932 image_to_lab: planar R,G,B (0..255) -> planar L,a*,b* (host, libm). */
 int faldoi_image_to_lab(const float *rgb, int nx, int ny, float *lab);
 

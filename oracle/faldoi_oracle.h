@@ -79,6 +79,10 @@ void orc_nltvcsad_global(const float *I0, const float *I1, const float *lab, int
                          float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
                          float *u1, float *u2);
 
+void orc_nltvl1_global(const float *I0, const float *I1, const float *lab, int pd,
+                       float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
+                       float *u1, float *u2);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

@@ -101,10 +101,31 @@ static int cmp_float(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
+static void nl_solver(int data_l1, const float *I0, const float *I1, const float *lab, int pd,
+                      float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
+                      float *u1, float *u2);
+
 /* src/global_faldoi.cpp:1642-1808.  u1,u2 in/out.  Duals start at zero (:1031). */
 void orc_nltvcsad_global(const float *I0, const float *I1, const float *lab, int pd,
                          float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
                          float *u1, float *u2)
+{
+    nl_solver(0, I0, I1, lab, pd, lambda, theta, tau, w, h, warps, max_inner, u1, u2);
+}
+
+/* NLTV-L1, nltvl1_PD, src/global_faldoi.cpp:1177-1327: the same non-local regulariser with the
+ * TV-L1 data term -- rho_c (:1232-1233) and the thresholding step (:1246-1272, identical to
+ * tvl2OF's :690-718) replace the CSAD selection. */
+void orc_nltvl1_global(const float *I0, const float *I1, const float *lab, int pd,
+                       float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
+                       float *u1, float *u2)
+{
+    nl_solver(1, I0, I1, lab, pd, lambda, theta, tau, w, h, warps, max_inner, u1, u2);
+}
+
+static void nl_solver(int data_l1, const float *I0, const float *I1, const float *lab, int pd,
+                      float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
+                      float *u1, float *u2)
 {
     const int n = w * h;
     const float l_t = lambda * theta;
@@ -129,7 +150,9 @@ void orc_nltvcsad_global(const float *I0, const float *I1, const float *lab, int
                 const int i = y * w + x;
                 const float Ix2 = I1wx[i] * I1wx[i], Iy2 = I1wy[i] * I1wy[i];
                 grad[i] = Ix2 + Iy2;
-                if (grad[i] > 1E-8) {                                           /* :1704 */
+                if (data_l1)                                                    /* rho_c reuses the I1w plane */
+                    I1w[i] = I1w[i] - I1wx[i] * u1[i] - I1wy[i] * u2[i] - I0[i];
+                if (!data_l1 && grad[i] > 1E-8) {                               /* :1704 */
                     int s = 0;
                     for (int k = -CS_R; k <= CS_R; k++)
                         for (int l = -CS_R; l <= CS_R; l++) {
@@ -155,7 +178,16 @@ void orc_nltvcsad_global(const float *I0, const float *I1, const float *lab, int
                     const int i = y * w + x;
                     v1[i] = u1[i];
                     v2[i] = u2[i];
-                    if (grad[i] > 1E-8) {
+                    if (data_l1) {                                               /* :1246-1272 */
+                        const float rho = I1w[i] + (I1wx[i] * u1[i] + I1wy[i] * u2[i]);
+                        float d1, d2;
+                        if (rho < -l_t * grad[i]) { d1 = l_t * I1wx[i]; d2 = l_t * I1wy[i]; }
+                        else if (rho > l_t * grad[i]) { d1 = -l_t * I1wx[i]; d2 = -l_t * I1wy[i]; }
+                        else if (grad[i] < 1E-8) { d1 = d2 = 0; }
+                        else { const float fi = -rho / grad[i]; d1 = fi * I1wx[i]; d2 = fi * I1wy[i]; }
+                        v1[i] = u1[i] + d1;
+                        v2[i] = u2[i] + d2;
+                    } else if (grad[i] > 1E-8) {
                         const float sg = sqrtf(grad[i]);
                         int it = 0, s = 0, nn = 0;
                         for (int k = -CS_R; k <= CS_R; k++)

@@ -87,6 +87,7 @@ def lib():
         L.orc_nltv_weights.argtypes = [_F, C.c_int, C.c_int, C.c_int, _F, _F]
         L.orc_nltvcsad_global.argtypes = [_F, _F, _F, C.c_int, C.c_float, C.c_float, C.c_float,
                                           C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]
+        L.orc_nltvl1_global.argtypes = L.orc_nltvcsad_global.argtypes
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads(cpu_share())      # libgomp may already be loaded (torch) with its own default
@@ -166,4 +167,14 @@ def nltvcsad_global(i0n, i1n, lab, u0, lam=0.85, theta=0.3, tau=0.1, warps=1, ma
     lab = f32(lab)
     lib().orc_nltvcsad_global(f32(i0n), f32(i1n), lab, lab.shape[0], lam, theta, tau, w, h, warps, max_inner,
                               u[0], u[1])
+    return u
+
+
+def nltvl1_global(i0n, i1n, lab, u0, lam=2.0, theta=0.3, tau=0.1, warps=1, max_inner=400):
+    """Reference parameter overrides for -m 2: src/global_faldoi.cpp:2146-2148."""
+    h, w = i0n.shape
+    u = f32(u0).copy()
+    lab = f32(lab)
+    lib().orc_nltvl1_global(f32(i0n), f32(i1n), lab, lab.shape[0], lam, theta, tau, w, h, warps, max_inner,
+                            u[0], u[1])
     return u

@@ -330,3 +330,17 @@ def test_global_faldoi_cli_method6_reproduces_the_reference_flo(tmp_path):
                         str(tmp_path / "out.flo"), "-m", "6", "-w", "1"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert hashlib.sha256((tmp_path / "out.flo").read_bytes()).hexdigest().startswith(case["flo_sha256_prefix"])
+
+
+@pytest.mark.parametrize("w,h,warps,inner", [(64, 48, 2, 30), (33, 21, 1, 50)])
+def test_nltvl1_bit_exact(ctx, oracle, w, h, warps, inner):
+    # NLTV-L1 (method 2): non-local regulariser + TV-L1 data term, src/global_faldoi.cpp:1177-1327
+    rng = np.random.default_rng(w + h)
+    i0n, i1n, gt = synthetic_pair(w, h, seed=h)
+    rgb = np.floor(np.stack([i0n, np.roll(i0n, 3, 1), i0n[::-1]]) * 255).astype(np.float32)
+    lab = F.capi.image_to_lab(rgb)
+    u0 = (gt + rng.standard_normal(gt.shape) * 0.3).astype(np.float32)
+    u, ms = ctx.nltvl1_global(i0n, i1n, lab, u0, warps=warps, max_inner=inner)
+    ou = oracle.nltvl1_global(i0n, i1n, lab, u0, warps=warps, max_inner=inner)
+    assert float(F.flo.epe(u, ou).mean()) <= EPE_GATE
+    assert bits_equal(u, ou), mismatch_report(u, ou)
