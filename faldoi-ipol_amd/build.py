@@ -31,7 +31,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-fno-gpu-flush-denormals-to-zero",
                # the SLP vectoriser packs fp32 pairs into v_pk_* ops, which on gfx950 cost two plain ops
                # plus the register moves that assemble the pairs (tools/ubench_valu.hip) -- a net loss here
-               "-fno-slp-vectorize"]
+               "-fno-slp-vectorize",
+               # keep the per-thread state arrays as individual registers: promoted to vector tuples,
+               # every conditionally updated row costs a copy of the whole tuple set (180 v_mov_b64)
+               "-mllvm", "-disable-promote-alloca-to-vector"]
 
 
 def hipcc():

@@ -249,25 +249,24 @@ __device__ __forceinline__ void dual_step(float &xi11, float &xi12, float &xi21,
     const float g21 = xi21 * xi21;
     const float g22 = xi22 * xi22;
     const float g = g11 + g12 + g21 + g22;
-    const float a11 = xi11 + tau * u1x;
-    const float a12 = xi12 + tau * u1y;
-    const float a21 = xi21 + tau * u2x;
-    const float a22 = xi22 + tau * u2y;
+    // numerators first, in place (the norm above already used the pre-update duals)
+    xi11 = xi11 + tau * u1x;
+    xi12 = xi12 + tau * u1y;
+    xi21 = xi21 + tau * u2x;
+    xi22 = xi22 + tau * u2y;
     // g <= 1  =>  sqrt(g) <= 1 (correctly rounded)  =>  max(1, sqrt(g)) == 1  =>  a / 1 == a.
     // When no lane of the wavefront has g > 1 the square root and the four quotients are skipped
     // as a whole (wave-uniform branch); otherwise every lane takes the general path, which
     // returns the same bits for the g <= 1 lanes.  (NaN g: both paths leave NaN duals.)
-    if (__builtin_amdgcn_ballot_w64(g > 1.0f) == 0ull) {
-        xi11 = a11; xi12 = a12; xi21 = a21; xi22 = a22;
-        return;
+    if (__builtin_amdgcn_ballot_w64(g > 1.0f) != 0ull) {
+        // max(1, sqrt(g)) == sqrt(max(1, g)): sqrt is monotone and sqrt(1) == 1 exactly
+        const float n = sqrt_ge1((g > 1.0f) ? g : 1.0f);
+        const double rn = recip_f64(n);             // one reciprocal, four exact quotients
+        xi11 = div_by(xi11, n, rn);
+        xi12 = div_by(xi12, n, rn);
+        xi21 = div_by(xi21, n, rn);
+        xi22 = div_by(xi22, n, rn);
     }
-    // max(1, sqrt(g)) == sqrt(max(1, g)): sqrt is monotone and sqrt(1) == 1 exactly
-    const float n = sqrt_ge1((g > 1.0f) ? g : 1.0f);
-    const double rn = recip_f64(n);                 // one reciprocal, four exact quotients
-    xi11 = div_by(a11, n, rn);
-    xi12 = div_by(a12, n, rn);
-    xi21 = div_by(a21, n, rn);
-    xi22 = div_by(a22, n, rn);
 }
 
 // :307-342 ofTVl2_getP for one pixel, followed by the over-relaxation of :780-783.
