@@ -360,15 +360,17 @@ __device__ __forceinline__ void tvl1_chunk_body(
             const float dn2 = (wv < NW - 1) ? s_ub2[wv < NW - 1 ? wv + 1 : wv][lane] : 0.0f;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
+                if (wv * R + r < need_lo - 1 || wv * R + r >= need_hi) continue;
+                // neighbours are fetched inside the executed block so the DPP moves fold into the
+                // subtractions (v_sub_f32_dpp)
                 const float r1 = lane_right(ub1[r]);
                 const float r2 = lane_right(ub2[r]);
                 const float d1 = (r < R - 1) ? ub1[r < R - 1 ? r + 1 : r] : dn1;
                 const float d2 = (r < R - 1) ? ub2[r < R - 1 ? r + 1 : r] : dn2;
                 const bool last_r = BORDER && (gy0 + r == ny - 1);
-                if (wv * R + r >= need_lo - 1 && wv * R + r < need_hi)
-                    dual_step(x11[r], x12[r], x21[r], x22[r],
-                              fwd_diff(r1, ub1[r], last_c), fwd_diff(d1, ub1[r], last_r),
-                              fwd_diff(r2, ub2[r], last_c), fwd_diff(d2, ub2[r], last_r), prm.tau);
+                dual_step(x11[r], x12[r], x21[r], x22[r],
+                          fwd_diff(r1, ub1[r], last_c), fwd_diff(d1, ub1[r], last_r),
+                          fwd_diff(r2, ub2[r], last_c), fwd_diff(d2, ub2[r], last_r), prm.tau);
             }
             s_x12[wv][lane] = x12[R - 1];
             s_x22[wv][lane] = x22[R - 1];
