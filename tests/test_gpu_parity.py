@@ -344,3 +344,39 @@ def test_nltvl1_bit_exact(ctx, oracle, w, h, warps, inner):
     ou = oracle.nltvl1_global(i0n, i1n, lab, u0, warps=warps, max_inner=inner)
     assert float(F.flo.epe(u, ou).mean()) <= EPE_GATE
     assert bits_equal(u, ou), mismatch_report(u, ou)
+
+
+# ------------------------------------------------------------------ shapes the tiling must survive
+@pytest.mark.parametrize("w,h", [(2, 2), (3, 200), (300, 2), (65, 65), (43, 45), (44, 44), (129, 7), (1, 1)])
+def test_tvl1_awkward_shapes(ctx, oracle, w, h):
+    if w < 2 or h < 2:
+        with pytest.raises(F.FaldoiError):
+            ctx.tvl1_global(np.zeros((h, w), np.float32), np.zeros((h, w), np.float32), np.zeros((2, h, w), np.float32))
+        return
+    rng = np.random.default_rng(w * 1000 + h)
+    i0n = rng.random((h, w)).astype(np.float32)
+    i1n = np.clip(i0n + rng.standard_normal((h, w)).astype(np.float32) * 0.05, 0, 1).astype(np.float32)
+    u0 = (rng.standard_normal((2, h, w)) * 0.7).astype(np.float32)
+    for chunk in (0, 3):
+        _compare_solve(ctx, oracle, i0n, i1n, u0, warps=2, max_inner=17, chunk=chunk)
+
+
+def test_tvl1_large_image_many_tiles(ctx, oracle):
+    # 2048x1100: 47 x 25 tiles, several workgroups per CU; stop test on
+    i0n, i1n, gt = synthetic_pair(2048, 1100, seed=77, amp=5.0)
+    _compare_solve(ctx, oracle, i0n, i1n, np.zeros_like(gt), warps=2, max_inner=25)
+
+
+def test_batch_of_many_small_pairs(ctx, oracle):
+    n, w, h = 37, 70, 50
+    b = F.Tvl1Batch(ctx, n, w, h)
+    pairs = [synthetic_pair(w, h, seed=100 + i, amp=0.5 + 0.1 * i) for i in range(n)]
+    for i, (a, c, gt) in enumerate(pairs):
+        b.upload(i, a, c, np.zeros_like(gt))
+    iters, errs, ms, nl = b.solve(warps=2, max_inner=60)
+    for i in (0, 5, 17, 36):
+        ou, oit, oerr, _ = oracle.tvl1_global(pairs[i][0], pairs[i][1], np.zeros((2, h, w), np.float32), warps=2,
+                                             max_inner=60)
+        assert list(iters[i]) == list(oit)
+        assert bits_equal(b.download(i), ou) and bits_equal(errs[i], oerr)
+    b.close()
