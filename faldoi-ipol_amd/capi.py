@@ -26,6 +26,7 @@ EXPORTS = [
     "faldoi_preprocess_global", "faldoi_tvl1_batch_upload_images",
     "faldoi_nltvcsad_default_params", "faldoi_nltvcsad_global", "faldoi_image_to_lab",
     "faldoi_nltvl1_default_params", "faldoi_nltvl1_global",
+    "faldoi_zoom_size", "faldoi_zoom_out", "faldoi_zoom_in",
 ]
 
 
@@ -105,6 +106,9 @@ def lib():
     L.faldoi_nltvl1_default_params.argtypes = [C.POINTER(NltvCsadParams)]
     L.faldoi_nltvl1_default_params.restype = None
     L.faldoi_nltvl1_global.argtypes = L.faldoi_nltvcsad_global.argtypes
+    L.faldoi_zoom_size.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.faldoi_zoom_out.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.c_float]
+    L.faldoi_zoom_in.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
     L.faldoi_selftest_division.argtypes = [vp, C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
@@ -215,6 +219,22 @@ class Context:
         """Mirror of nltvl1_PD.  Returns (u, device ms)."""
         return self._nl_global(lib().faldoi_nltvl1_default_params, lib().faldoi_nltvl1_global,
                                i0n, i1n, lab, u0, params)
+
+    def zoom_out(self, img, factor):
+        img = _f32(img)
+        h, w = img.shape
+        ww, hh = C.c_int(), C.c_int()
+        _check(lib().faldoi_zoom_size(w, h, factor, C.byref(ww), C.byref(hh)))
+        out = np.empty((hh.value, ww.value), np.float32)
+        _check(lib().faldoi_zoom_out(self._h, img, out, w, h, factor))
+        return out
+
+    def zoom_in(self, img, ww, hh):
+        img = _f32(img)
+        h, w = img.shape
+        out = np.empty((hh, ww), np.float32)
+        _check(lib().faldoi_zoom_in(self._h, img, out, w, h, ww, hh))
+        return out
 
     def selftest_division(self, count=1 << 28, seed=12345):
         bad = C.c_ulonglong(0)

@@ -164,6 +164,7 @@ extern "C" int faldoi_ctx_synchronize(faldoi_ctx *c)
 }
 
 static float *plane_ptr(faldoi_tvl1_batch *b, int pair, int plane);
+static int prim_check(faldoi_ctx *ctx, int nx, int ny);
 
 // ------------------------------------------------------------------------------------------ tiling
 struct TileCfg {
@@ -577,6 +578,83 @@ static int gaussian_taps(float sigma, GaussTaps *t)
     for (int i = size; i < kMaxGaussTaps; i++) t->B[i] = 0.f;
     t->size = size;
     return size;
+}
+
+// The C copy (src/mask.c:248-340, what src/zoom.c links): same text, but `exp` is the double function.
+static int gaussian_taps_c(float sigma, GaussTaps *t)
+{
+    const float den = 2 * sigma * sigma;
+    const int size = (int)(5 * sigma) + 1;
+    if (!(sigma > 0) || size > kMaxGaussTaps) return -1;
+    for (int i = 0; i < size; i++)
+        t->B[i] = (float)(1 / (sigma * std::sqrt(2.0 * 3.1415926)) * std::exp((double)(-i * i / den)));
+    float norm = 0;
+    for (int i = 0; i < size; i++) norm += t->B[i];
+    norm *= 2;
+    norm -= t->B[0];
+    for (int i = 0; i < size; i++) t->B[i] /= norm;
+    for (int i = size; i < kMaxGaussTaps; i++) t->B[i] = 0.f;
+    t->size = size;
+    return size;
+}
+
+// ---- pyramid resampling, src/zoom.c ----
+extern "C" int faldoi_zoom_size(int nx, int ny, float factor, int *nxx, int *nyy)
+{
+    if (!nxx || !nyy) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    *nxx = (int)((float)nx * factor + 0.5);          // src/zoom.c:29-30
+    *nyy = (int)((float)ny * factor + 0.5);
+    return FALDOI_OK;
+}
+
+static int zoom_run(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, int nxx, int nyy, float fx, float fy,
+                    const GaussTaps *taps)
+{
+    const size_t n = (size_t)nx * ny, m = (size_t)nxx * nyy;
+    DevBuf buf;
+    HIP_TRY(hipMalloc((void **)&buf.p, sizeof(float) * (2 * n + m)));
+    float *src = buf.p, *tmp = buf.p + n, *dst = buf.p + 2 * n;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(src, I, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (taps) {
+        hipLaunchKernelGGL(gaussian_pass_kernel<false>, dim3(blocks), dim3(256), 0, s, src, tmp, nx, ny, *taps);
+        hipLaunchKernelGGL(gaussian_pass_kernel<true>, dim3(blocks), dim3(256), 0, s, tmp, src, nx, ny, *taps);
+    }
+    const int oblocks = (int)((m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048);
+    hipLaunchKernelGGL(zoom_resample_kernel, dim3(oblocks), dim3(256), 0, s, src, dst, nx, ny, nxx, nyy, fx, fy);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(Iout, dst, sizeof(float) * m, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_zoom_out(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, float factor)
+{
+    if (!ctx || !I || !Iout) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    if (!(factor > 0.f) || !(factor < 1.f)) return fail(FALDOI_ERR_INVALID, "zoom factor %g outside (0,1)", (double)factor);
+    int rc = prim_check(ctx, nx, ny);
+    if (rc) return rc;
+    int nxx, nyy;
+    faldoi_zoom_size(nx, ny, factor, &nxx, &nyy);
+    if (nxx < 1 || nyy < 1) return fail(FALDOI_ERR_INVALID, "zoomed size %dx%d is empty", nxx, nyy);
+    const float sigma = (float)(0.6 * std::sqrt(1.0 / (factor * factor) - 1.0));       // src/zoom.c:54 (ZOOM_SIGMA_ZERO)
+    GaussTaps taps;
+    const int size = gaussian_taps_c(sigma, &taps);
+    if (size < 0 || size > nx || size > ny)
+        return fail(FALDOI_ERR_INVALID, "image %dx%d too small (or factor %g too small) for the %d-tap pre-smoothing", nx, ny,
+                    (double)factor, size);
+    return zoom_run(ctx, I, Iout, nx, ny, nxx, nyy, factor, factor, &taps);
+}
+
+extern "C" int faldoi_zoom_in(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
+{
+    if (!ctx || !I || !Iout) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    int rc = prim_check(ctx, nx, ny);
+    if (rc) return rc;
+    if (nxx < 1 || nyy < 1 || (long)nxx * nyy > (1L << 28)) return fail(FALDOI_ERR_INVALID, "bad zoomed size %dx%d", nxx, nyy);
+    const float fx = ((float)nxx / nx), fy = ((float)nyy / ny);                         // src/zoom.c:92-93
+    return zoom_run(ctx, I, Iout, nx, ny, nxx, nyy, fx, fy, nullptr);
 }
 
 // Device-side pipeline on three gray planes already in HBM (A = i0, B = i1, C = i_1), in place.

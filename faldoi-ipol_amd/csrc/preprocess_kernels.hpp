@@ -120,4 +120,19 @@ __global__ void gaussian_pass_kernel(const float *__restrict__ in, float *__rest
     }
 }
 
+// src/zoom.c:59-73 / :96-105: bicubic samples of `in` (nx x ny) at (j / fx, i / fy) for an nxx x nyy
+// output; taps are clamped to the image (border_out = false), never zeroed.
+__global__ void zoom_resample_kernel(const float *__restrict__ in, float *__restrict__ out, int nx, int ny, int nxx,
+                                     int nyy, float fx, float fy)
+{
+    const int n = nxx * nyy;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const int i1 = p / nxx, j1 = p - i1 * nxx;
+        const float i2 = (float)i1 / fy;
+        const float j2 = (float)j1 / fx;
+        const BicubicTaps t = bicubic_taps(j2, i2, nx, ny);
+        out[p] = bicubic_eval(in, t, nx);
+    }
+}
+
 }  // namespace faldoi

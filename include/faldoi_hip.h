@@ -148,6 +148,15 @@ int faldoi_preprocess_global(faldoi_ctx *ctx, const float *i0, const float *i1, 
 int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
                                     const float *im1, int pd, const float *u, const float *xi);
 
+/* ---------------------------------------------------------------- pyramid resampling
+ * src/zoom.c:19-106 (zoom_size, zoom_out, zoom_in).  The reference never compiles or calls
+ * zoom.c (src/CMakeLists.txt:45); it is provided because the resampler belongs to the same family
+ * of primitives (Gaussian of src/mask.c + bicubic with clamped taps).  Host buffers.
+ * zoom_out: Iout has the size faldoi_zoom_size returns; 0 < factor < 1. */
+int faldoi_zoom_size(int nx, int ny, float factor, int *nxx, int *nyy);
+int faldoi_zoom_out(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, float factor);
+int faldoi_zoom_in(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, int nxx, int nyy);
+
 /* ---------------------------------------------------------------- NLTV-CSAD functional (method 6)
  * Replaces  void nltvcsad_PD(const float *I0, float *I1, float *a, int pd, lambda, theta, tau, w, h,
  *                            warps, verbose, float *u1, float *u2)      src/global_faldoi.cpp:1642-1808

@@ -261,6 +261,23 @@ int orc_gaussian_taps(float sigma, float *B, int maxn)
     return size;
 }
 
+/* The C copy of the Gaussian (src/mask.c:248-340, the one zoom.c links against): identical text,
+ * but in C `exp` is the double function, so the exponent is evaluated in double. */
+int orc_gaussian_taps_c(float sigma, float *B, int maxn)
+{
+    const float den = 2 * sigma * sigma;
+    const int size = (int)(5 * sigma) + 1;
+    if (size > maxn) return -1;
+    for (int i = 0; i < size; i++)
+        B[i] = (float)(1 / (sigma * sqrt(2.0 * 3.1415926)) * exp(-i * i / den));
+    float norm = 0;
+    for (int i = 0; i < size; i++) norm += B[i];
+    norm *= 2;
+    norm -= B[0];
+    for (int i = 0; i < size; i++) B[i] /= norm;
+    return size;
+}
+
 /* Index of the sample the reference's padded line buffer holds at virtual position i
  * (src/utils.cpp:566-571,600-605, "reflecting"): the left/top pad mirrors WITHOUT repeating
  * the edge sample, the right/bottom pad mirrors WITH it. */
@@ -284,12 +301,28 @@ static void gaussian_line(const float *src, int n, int stride, const float *B, i
     }
 }
 
+static void gaussian_with_taps(float *I, int xdim, int ydim, const float *B, int size);
+
 /* src/utils.cpp:521-630: separable, rows first, then columns on the row-filtered image. */
 void orc_gaussian(float *I, int xdim, int ydim, float sigma)
 {
     float B[64];
     const int size = orc_gaussian_taps(sigma, B, 64);
     if (size < 0 || size > xdim || size >= ydim + 1) abort();
+    gaussian_with_taps(I, xdim, ydim, B, size);
+}
+
+/* src/mask.c:248 (C linkage copy) */
+void orc_gaussian_c(float *I, int xdim, int ydim, float sigma)
+{
+    float B[64];
+    const int size = orc_gaussian_taps_c(sigma, B, 64);
+    if (size < 0 || size > xdim || size >= ydim + 1) abort();
+    gaussian_with_taps(I, xdim, ydim, B, size);
+}
+
+static void gaussian_with_taps(float *I, int xdim, int ydim, const float *B, int size)
+{
 
 #pragma omp parallel
     {
@@ -465,4 +498,50 @@ long orc_tvl1_global(const float *I0, const float *I1, float *u1, float *u2,
     }
     free(buf);
     return total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Pyramid resampling, src/zoom.c (not compiled into the reference's executables; restated because
+ * the north star names it).
+ * ---------------------------------------------------------------------------------------- */
+
+/* src/zoom.c:19-31 */
+void orc_zoom_size(int nx, int ny, int *nxx, int *nyy, float factor)
+{
+    *nxx = (int)((float)nx * factor + 0.5);
+    *nyy = (int)((float)ny * factor + 0.5);
+}
+
+/* src/zoom.c:38-76: Gaussian (mask.c copy) with sigma = 0.6*sqrt(1/f^2 - 1), then bicubic samples at
+ * (j/f, i/f) with clamped taps (border_out = false). */
+void orc_zoom_out(const float *I, float *Iout, int nx, int ny, float factor)
+{
+    float *Is = (float *)malloc(sizeof(float) * (size_t)nx * ny);
+    memcpy(Is, I, sizeof(float) * (size_t)nx * ny);
+    int nxx, nyy;
+    orc_zoom_size(nx, ny, &nxx, &nyy, factor);
+    const float sigma = (float)(0.6 * sqrt(1.0 / (factor * factor) - 1.0));
+    orc_gaussian_c(Is, nx, ny, sigma);
+#pragma omp parallel for
+    for (int i1 = 0; i1 < nyy; i1++)
+        for (int j1 = 0; j1 < nxx; j1++) {
+            const float i2 = (float)i1 / factor;
+            const float j2 = (float)j1 / factor;
+            Iout[i1 * nxx + j1] = orc_bicubic_at(Is, j2, i2, nx, ny, 0);
+        }
+    free(Is);
+}
+
+/* src/zoom.c:82-106 */
+void orc_zoom_in(const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
+{
+    const float factorx = ((float)nxx / nx);
+    const float factory = ((float)nyy / ny);
+#pragma omp parallel for
+    for (int i1 = 0; i1 < nyy; i1++)
+        for (int j1 = 0; j1 < nxx; j1++) {
+            const float i2 = (float)i1 / factory;
+            const float j2 = (float)j1 / factorx;
+            Iout[i1 * nxx + j1] = orc_bicubic_at(I, j2, i2, nx, ny, 0);
+        }
 }

@@ -42,6 +42,12 @@ void orc_image_normalization_2(const float *I0, const float *I1, float *I0n, flo
 void orc_gaussian(float *I, int xdim, int ydim, float sigma);
 /* normalised half-kernel B[0..size) as src/utils.cpp:529-552 builds it; returns size */
 int orc_gaussian_taps(float sigma, float *B, int maxn);
+/* src/mask.c:248 copy of the Gaussian (exp in double) and src/zoom.c:19-106 */
+int orc_gaussian_taps_c(float sigma, float *B, int maxn);
+void orc_gaussian_c(float *I, int xdim, int ydim, float sigma);
+void orc_zoom_size(int nx, int ny, int *nxx, int *nyy, float factor);
+void orc_zoom_out(const float *I, float *Iout, int nx, int ny, float factor);
+void orc_zoom_in(const float *I, float *Iout, int nx, int ny, int nxx, int nyy);
 /* gray -> normalise_3 -> gaussian(0.9) exactly as global_faldoi's main does before the solver.
  * i0,i1,im1: planar images with pd channels (pd==1 or 3), values 0..255.  Outputs w*h each. */
 void orc_preprocess_global(const float *i0, const float *i1, const float *im1, int w, int h, int pd,

@@ -75,6 +75,10 @@ def lib():
         L.orc_image_normalization_2.argtypes = [_F, _F, _F, _F, C.c_int]
         L.orc_gaussian.argtypes = [_F, C.c_int, C.c_int, C.c_float]
         L.orc_gaussian_taps.argtypes = [C.c_float, _F, C.c_int]
+        L.orc_gaussian_c.argtypes = [_F, C.c_int, C.c_int, C.c_float]
+        L.orc_zoom_size.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_float]
+        L.orc_zoom_out.argtypes = [_F, _F, C.c_int, C.c_int, C.c_float]
+        L.orc_zoom_in.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_preprocess_global.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int, _F, _F, _F]
         L.orc_tvl1_global.argtypes = [_F, _F, _F, _F, _F, _F, _F, _F,
                                       C.c_float, C.c_float, C.c_float, C.c_float,
@@ -112,6 +116,10 @@ def ref():
         R.ref_bicubic_at.argtypes = [_F, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         R.ref_bicubic_at.restype = C.c_float
         R.ref_bicubic_warp.argtypes = [_F, _F, _F, _F, C.c_int, C.c_int, C.c_int]
+        if hasattr(R, "ref_zoom_out"):
+            R.ref_zoom_size.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_float]
+            R.ref_zoom_out.argtypes = [_F, _F, C.c_int, C.c_int, C.c_float]
+            R.ref_zoom_in.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
         _ref = R
     return _ref
 
@@ -178,3 +186,26 @@ def nltvl1_global(i0n, i1n, lab, u0, lam=2.0, theta=0.3, tau=0.1, warps=1, max_i
     lib().orc_nltvl1_global(f32(i0n), f32(i1n), lab, lab.shape[0], lam, theta, tau, w, h, warps, max_inner,
                             u[0], u[1])
     return u
+
+
+def zoom_size(nx, ny, factor):
+    a, b = C.c_int(), C.c_int()
+    lib().orc_zoom_size(nx, ny, C.byref(a), C.byref(b), factor)
+    return a.value, b.value
+
+
+def zoom_out(img, factor):
+    img = f32(img)
+    h, w = img.shape
+    ww, hh = zoom_size(w, h, factor)
+    out = np.empty((hh, ww), np.float32)
+    lib().orc_zoom_out(img, out, w, h, factor)
+    return out
+
+
+def zoom_in(img, ww, hh):
+    img = f32(img)
+    h, w = img.shape
+    out = np.empty((hh, ww), np.float32)
+    lib().orc_zoom_in(img, out, w, h, ww, hh)
+    return out

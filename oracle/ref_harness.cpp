@@ -8,6 +8,7 @@
 #include "utils.h"                       // reference: src/utils.h
 extern "C" {
 #include "bicubic_interpolation.h"       // reference: src/bicubic_interpolation.h
+#include "zoom.h"                        // reference: src/zoom.h (zoom.c is compiled with mask.c, as it includes mask.h)
 }
 
 extern "C" {
@@ -40,5 +41,14 @@ float ref_bicubic_at(const float *in, float uu, float vv, int nx, int ny, int bo
 void ref_bicubic_warp(const float *in, const float *u, const float *v, float *out,
                       int nx, int ny, int border_out)
 { bicubic_interpolation_warp(in, u, v, out, nx, ny, border_out != 0); }     // src/bicubic_interpolation.c:245
+
+void ref_zoom_size(int nx, int ny, int *nxx, int *nyy, float factor)
+{ zoom_size(nx, ny, nxx, nyy, factor); }                          // src/zoom.c:19
+
+void ref_zoom_out(const float *I, float *Iout, int nx, int ny, float factor)
+{ zoom_out(I, Iout, nx, ny, factor); }                            // src/zoom.c:38
+
+void ref_zoom_in(const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
+{ zoom_in(I, Iout, nx, ny, nxx, nyy); }                           // src/zoom.c:82
 
 }  // extern "C"

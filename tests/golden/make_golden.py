@@ -72,6 +72,16 @@ def main():
     for bo in (0, 1):
         out["at_bo%d" % bo] = np.array(
             [R.ref_bicubic_at(img, float(p[0]), float(p[1]), w, h, bo) for p in pts], np.float32)
+    # src/zoom.c (compiled from the reference with mask.c): down- and up-sampling
+    import ctypes as C
+    for tag, f in (("050", 0.5), ("075", 0.75)):
+        ww, hh = C.c_int(), C.c_int()
+        R.ref_zoom_size(w, h, C.byref(ww), C.byref(hh), f)
+        zo = np.empty((hh.value, ww.value), np.float32)
+        R.ref_zoom_out(img, zo, w, h, f)
+        zi = np.empty((h, w), np.float32)
+        R.ref_zoom_in(zo, zi, ww.value, hh.value, w, h)
+        out["zoom_out_" + tag], out["zoom_in_" + tag] = zo, zi
     np.savez_compressed(os.path.join(HERE, "ref_primitives.npz"), **out)
     print("wrote ref_primitives.npz with", len(out), "arrays")
 

@@ -380,3 +380,22 @@ def test_batch_of_many_small_pairs(ctx, oracle):
         assert list(iters[i]) == list(oit)
         assert bits_equal(b.download(i), ou) and bits_equal(errs[i], oerr)
     b.close()
+
+
+def test_zoom_resampler_bit_exact(ctx, oracle):
+    # src/zoom.c on the GPU against the oracle (itself pinned to the reference's zoom.c objects)
+    g = np.load(GOLDEN + "/ref_primitives.npz")
+    h, w = g["img"].shape
+    for tag, f in (("050", 0.5), ("075", 0.75)):
+        zo = ctx.zoom_out(g["img"], f)
+        assert bits_equal(zo, g["zoom_out_" + tag])
+        assert bits_equal(ctx.zoom_in(zo, w, h), g["zoom_in_" + tag])
+    i0, _ = sintel_pair()
+    gray = oracle.preprocess_global(i0, i0)[0]
+    for f in (0.5, 0.35):
+        a = ctx.zoom_out(gray, f)
+        b = oracle.zoom_out(gray, f)
+        assert bits_equal(a, b), f
+        assert bits_equal(ctx.zoom_in(a, 1024, 436), oracle.zoom_in(b, 1024, 436))
+    with pytest.raises(F.FaldoiError):
+        ctx.zoom_out(gray, 1.5)
