@@ -25,7 +25,7 @@ BYTES_PER_PX_WARP = 44        # per outer warp (bicubic gathers + constants)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # HBM bytes per launch of tvl1_chunk_kernel from rocprofv3 PMC passes (profiles/): filled in from the
 # committed counter summaries; None until measured for the current kernel.
-TRAFFIC_BYTES_PER_LAUNCH = 36303872   # (2*10739 + 13975) KB, profiles/r01_pmc_sq_v5.md (1024x436, k=10)
+TRAFFIC_BYTES_PER_LAUNCH = 36303872   # (2*10739 + 13975) KB, profiles/r01_pmc_sq.md (1024x436, k=10)
 
 
 def main():

@@ -106,9 +106,12 @@ void faldoi_tvl1_batch_destroy(faldoi_tvl1_batch *b);
 /* Host -> HBM.  xi may be NULL (zero).  Resets the pair's state. */
 int faldoi_tvl1_batch_upload(faldoi_tvl1_batch *b, int pair, const float *I0, const float *I1,
                              const float *u, const float *xi);
-/* Restore the flow/duals uploaded last (device-to-device), so a solve can be repeated. */
+/* Invalidates the last result.  Every batch_solve starts from the flow/duals that were uploaded
+ * (kept in their own planes), so a solve can be repeated without uploading again; this call only
+ * makes a following download fail until the next solve. */
 int faldoi_tvl1_batch_reset(faldoi_tvl1_batch *b);
-/* Runs the whole solve for every pair; stats may be NULL or an array of npairs entries. */
+/* Runs the whole solve for every pair, starting from the uploaded state; stats may be NULL or an
+ * array of npairs entries. */
 int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm,
                             faldoi_tvl1_stats *stats);
 /* HBM -> host.  u: 2*nx*ny; xi: 4*nx*ny or NULL. */
