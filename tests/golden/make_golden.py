@@ -8,6 +8,8 @@ source text is stored.  The GPU box and CPU-only CI read the .npz and never need
 Also committed next to it:
   sintel_clean_easy_frame_000{2,3}.png  -- the reference's example_data/clean/easy frames (inputs
                                            of BASELINE configs 1/2), copied verbatim as data files.
+  sintel_final_hard_frame_000{2,3}.png  -- example_data/final/hard frames (a large-motion pair for the
+                                           GPU == oracle test; no reference output recorded for it).
   known_answers.json                    -- what the compiled reference produced for whole solves
                                            (iteration counts, sha256 of the .flo), SURVEY.md App. D.
 """

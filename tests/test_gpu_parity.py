@@ -399,3 +399,17 @@ def test_zoom_resampler_bit_exact(ctx, oracle):
         assert bits_equal(ctx.zoom_in(a, 1024, 436), oracle.zoom_in(b, 1024, 436))
     with pytest.raises(F.FaldoiError):
         ctx.zoom_out(gray, 1.5)
+
+
+def test_second_sintel_pair_large_motion(ctx, oracle):
+    # example_data/final/hard frames 2->3 (motion blur, displacements up to ~39 px, never meets the
+    # tolerance: 5 x 400 iterations).  No reference output was recorded for this pair, so the check is
+    # GPU == oracle (bit for bit), through the device-side preprocessing as well.
+    from util import load_rgb_planar
+    i0 = load_rgb_planar(GOLDEN + "/sintel_final_hard_frame_0002.png")
+    i1 = load_rgb_planar(GOLDEN + "/sintel_final_hard_frame_0003.png")
+    o0, o1 = oracle.preprocess_global(i0, i1)
+    g0, g1 = ctx.preprocess_global(i0, i1)
+    assert bits_equal(g0, o0) and bits_equal(g1, o1)
+    u = _compare_solve(ctx, oracle, g0, g1, np.zeros((2, 436, 1024), np.float32))
+    assert float(np.abs(u).max()) > 30.0
