@@ -88,6 +88,21 @@ __device__ __forceinline__ float sqrt_ge1(float x)
     return r;
 }
 
+// The reference's |g| written as sqrt(g*g) (src/global_faldoi.cpp:1151).  In radix 2 with round-to-
+// nearest, sqrt(RN(g*g)) == |g| exactly whenever g*g neither underflows nor overflows (and for
+// g == 0); outside that range the IEEE sequence is evaluated.  The branch is wave-uniform.  The
+// identity is checked on the GPU for every float of the fast range by faldoi_selftest_division.
+__device__ __forceinline__ bool sqrt_of_square_is_abs(float g)
+{
+    const float a = __builtin_fabsf(g);
+    return (a >= 0x1p-60f && a <= 0x1p60f) || a == 0.0f;
+}
+__device__ __forceinline__ float sqrt_of_square(float g)
+{
+    if (__builtin_amdgcn_ballot_w64(!sqrt_of_square_is_abs(g)) == 0ull) return __builtin_fabsf(g);
+    return __builtin_sqrtf(g * g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stencil classes of a pixel (its position relative to the image frame).
 // ---------------------------------------------------------------------------------------------

@@ -898,7 +898,7 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
     DevBuf buf;
     HIP_TRY(hipMalloc((void **)&buf.p, sizeof(float) * pe * N_COUNT));
     float *base = buf.p;
-    HIP_TRY(hipMemsetAsync(base, 0, sizeof(float) * pe * N_COUNT, s));          // duals and b start at 0 (:1031,:1347)
+    HIP_TRY(hipMemsetAsync(base, 0, sizeof(float) * pe * N_COUNT, s));          // duals start at 0 (:1031)
     HIP_TRY(hipMemcpyAsync(base + N_I0 * pe, I0, nb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(base + N_I1 * pe, I1, nb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(base + N_U1 * pe, u, nb, hipMemcpyHostToDevice, s));
@@ -914,7 +914,6 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
                        nx, ny, (size_t)0, (size_t)0, 1);                        // :1690
     for (int w = 0; w < prm->warps; ++w) {
         hipLaunchKernelGGL(nl_warp_kernel, grid, block, 0, s, base, pe, nx, ny, data_l1 ? 1 : 0);
-        if (!data_l1) hipLaunchKernelGGL(nl_csad_terms_kernel, grid, block, 0, s, base, pe, nx, ny);
         for (int it = 0; it < prm->max_inner; ++it) {                           // :1729 / :1240, no tolerance test
             hipLaunchKernelGGL(nl_dual_kernel, grid, block, 0, s, base, pe, nx, ny, prm->tau);
             if (data_l1)

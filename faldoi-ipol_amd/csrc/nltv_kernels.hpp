@@ -28,8 +28,9 @@ enum NlPlane {
     N_P,                                   // 24 planes
     N_Q = N_P + kNlSlots,                  // 24 planes
     N_W = N_Q + kNlSlots,                  // 24 planes
-    N_B = N_W + kNlSlots,                  // 48 planes
-    N_COUNT = N_B + kCsSlots
+    N_T1 = N_W + kNlSlots,                 // I1wx*u1 and I1wy*u2 at the start of the warp (CSAD terms)
+    N_T2,
+    N_COUNT
 };
 
 // Per-warp: three bicubic warps (border_out = true), grad = I1wx^2 + I1wy^2, ubar = u (:1694-1725)
@@ -51,37 +52,19 @@ __global__ __launch_bounds__(256) void nl_warp_kernel(float *__restrict__ base, 
     base[N_I1WX * pe + p] = wx;
     base[N_I1WY * pe + p] = wy;
     base[N_GRAD * pe + p] = grad_sq(wx, wy);
+    base[N_T1 * pe + p] = wx * u1;                              // the two products inside b (:1716-1717)
+    base[N_T2 * pe + p] = wy * u2;
     base[N_UB1 * pe + p] = u1;
     base[N_UB2 * pe + p] = u2;
 }
 
-// Per-warp: CSAD terms b_s for the 48 neighbours, only where grad > GRAD_IS_ZERO; elsewhere the
-// previous value stays (:1704-1719).  grad > 1E-8 (double) <=> !(grad < grad_zero_bound()).
-__global__ __launch_bounds__(256) void nl_csad_terms_kernel(float *__restrict__ base, size_t pe, int nx, int ny)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nx * ny) return;
-    const int y = i / nx, x = i - y * nx;
-    const float grad = base[N_GRAD * pe + i];
-    if (grad < grad_zero_bound()) return;
-    const float *I0 = base + N_I0 * pe, *I1w = base + N_I1W * pe;
-    const float i0 = I0[i], i1w = I1w[i];
-    const float t1 = base[N_I1WX * pe + i] * base[N_U1 * pe + i];
-    const float t2 = base[N_I1WY * pe + i] * base[N_U2 * pe + i];
-    const float sg = __builtin_sqrtf(grad);
-    int s = 0;
-#pragma unroll
-    for (int k = -kCsR; k <= kCsR; ++k)
-#pragma unroll
-        for (int l = -kCsR; l <= kCsR; ++l) {
-            if (k == 0 && l == 0) continue;
-            if (x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny) {
-                const int pos = i + k * nx + l;
-                base[(size_t)(N_B + s) * pe + i] = (i0 - I0[pos] - i1w + I1w[pos] + t1 + t2) / sg;   // :1716-1717
-            }
-            ++s;
-        }
-}
+// The CSAD terms of the reference (PosNei::b[48], :1704-1719)
+//     b_s = (I0[i] - I0[pos_s] - I1w[i] + I1w[pos_s] + I1wx[i]*u1[i] + I1wy[i]*u2[i]) / sqrt(grad[i])
+// are per-warp constants that the reference stores (48 floats per pixel) and re-reads every
+// iteration.  Here they are recomputed inside the data step from I0, I1w (7x7 neighbourhoods, served
+// by L1/L2) and the two warp-start products: 48 planes (86 MB at 1024x436) less traffic per
+// iteration and less HBM footprint.  The reference only refreshes b where grad > GRAD_IS_ZERO and
+// only reads it there (:1737), so recomputing is equivalent.
 
 // ofnltv_getD (:1127-1174) on ubar: for every valid slot
 //   g = w * (ubar_i - ubar_j) / wt;  p <- (p + tau*g) / (1 + tau*sqrt(g*g))     (same for q with ubar2)
@@ -92,6 +75,7 @@ __global__ __launch_bounds__(256) void nl_dual_kernel(float *__restrict__ base, 
     const int y = i / nx, x = i - y * nx;
     const float *ub1 = base + N_UB1 * pe, *ub2 = base + N_UB2 * pe;
     const float a1 = ub1[i], a2 = ub2[i], wt = base[N_WT * pe + i];
+    const double rwt = recip_f64(wt);        // wt > 0 (every pixel has valid neighbours): shared by 48 quotients
     int s = 0;
 #pragma unroll
     for (int k = -kNlR; k <= kNlR; ++k)
@@ -102,18 +86,56 @@ __global__ __launch_bounds__(256) void nl_dual_kernel(float *__restrict__ base, 
                 const int ap = i + k * nx + l;
                 const float w = base[(size_t)(N_W + s) * pe + i];
                 float *pp = base + (size_t)(N_P + s) * pe + i, *qq = base + (size_t)(N_Q + s) * pe + i;
-                const float g1 = w * (a1 - ub1[ap]) / wt;
-                const float d1 = 1 + tau * __builtin_sqrtf(g1 * g1);
+                const float g1 = div_by(w * (a1 - ub1[ap]), wt, rwt);
+                const float d1 = 1 + tau * sqrt_of_square(g1);
                 *pp = (*pp + tau * g1) / d1;
-                const float g2 = w * (a2 - ub2[ap]) / wt;
-                const float d2 = 1 + tau * __builtin_sqrtf(g2 * g2);
+                const float g2 = div_by(w * (a2 - ub2[ap]), wt, rwt);
+                const float d2 = 1 + tau * sqrt_of_square(g2);
                 *qq = (*qq + tau * g2) / d2;
             }
             ++s;
         }
 }
 
-// Compare-exchange network: bitonic sort of 64 registers, ascending (static indices only).
+// Compare-exchange network for the 48 CSAD terms held in registers: Batcher's odd-even merge sort
+// for 64 inputs with every comparator that touches an index >= 48 removed (those inputs would be
+// +inf and never move) -- 384 comparators instead of the 672 of a 64-input bitonic network.
+// Generated and 0/1-checked by the script quoted in DESIGN.md section 3.4.
+struct CxPair { unsigned char a, b; };
+__device__ constexpr CxPair kSort48[384] = {
+    {0,1}, {2,3}, {0,2}, {1,3}, {1,2}, {4,5}, {6,7}, {4,6}, {5,7}, {5,6}, {0,4}, {2,6},
+    {2,4}, {1,5}, {3,7}, {3,5}, {1,2}, {3,4}, {5,6}, {8,9}, {10,11}, {8,10}, {9,11}, {9,10},
+    {12,13}, {14,15}, {12,14}, {13,15}, {13,14}, {8,12}, {10,14}, {10,12}, {9,13}, {11,15}, {11,13}, {9,10},
+    {11,12}, {13,14}, {0,8}, {4,12}, {4,8}, {2,10}, {6,14}, {6,10}, {2,4}, {6,8}, {10,12}, {1,9},
+    {5,13}, {5,9}, {3,11}, {7,15}, {7,11}, {3,5}, {7,9}, {11,13}, {1,2}, {3,4}, {5,6}, {7,8},
+    {9,10}, {11,12}, {13,14}, {16,17}, {18,19}, {16,18}, {17,19}, {17,18}, {20,21}, {22,23}, {20,22}, {21,23},
+    {21,22}, {16,20}, {18,22}, {18,20}, {17,21}, {19,23}, {19,21}, {17,18}, {19,20}, {21,22}, {24,25}, {26,27},
+    {24,26}, {25,27}, {25,26}, {28,29}, {30,31}, {28,30}, {29,31}, {29,30}, {24,28}, {26,30}, {26,28}, {25,29},
+    {27,31}, {27,29}, {25,26}, {27,28}, {29,30}, {16,24}, {20,28}, {20,24}, {18,26}, {22,30}, {22,26}, {18,20},
+    {22,24}, {26,28}, {17,25}, {21,29}, {21,25}, {19,27}, {23,31}, {23,27}, {19,21}, {23,25}, {27,29}, {17,18},
+    {19,20}, {21,22}, {23,24}, {25,26}, {27,28}, {29,30}, {0,16}, {8,24}, {8,16}, {4,20}, {12,28}, {12,20},
+    {4,8}, {12,16}, {20,24}, {2,18}, {10,26}, {10,18}, {6,22}, {14,30}, {14,22}, {6,10}, {14,18}, {22,26},
+    {2,4}, {6,8}, {10,12}, {14,16}, {18,20}, {22,24}, {26,28}, {1,17}, {9,25}, {9,17}, {5,21}, {13,29},
+    {13,21}, {5,9}, {13,17}, {21,25}, {3,19}, {11,27}, {11,19}, {7,23}, {15,31}, {15,23}, {7,11}, {15,19},
+    {23,27}, {3,5}, {7,9}, {11,13}, {15,17}, {19,21}, {23,25}, {27,29}, {1,2}, {3,4}, {5,6}, {7,8},
+    {9,10}, {11,12}, {13,14}, {15,16}, {17,18}, {19,20}, {21,22}, {23,24}, {25,26}, {27,28}, {29,30}, {32,33},
+    {34,35}, {32,34}, {33,35}, {33,34}, {36,37}, {38,39}, {36,38}, {37,39}, {37,38}, {32,36}, {34,38}, {34,36},
+    {33,37}, {35,39}, {35,37}, {33,34}, {35,36}, {37,38}, {40,41}, {42,43}, {40,42}, {41,43}, {41,42}, {44,45},
+    {46,47}, {44,46}, {45,47}, {45,46}, {40,44}, {42,46}, {42,44}, {41,45}, {43,47}, {43,45}, {41,42}, {43,44},
+    {45,46}, {32,40}, {36,44}, {36,40}, {34,42}, {38,46}, {38,42}, {34,36}, {38,40}, {42,44}, {33,41}, {37,45},
+    {37,41}, {35,43}, {39,47}, {39,43}, {35,37}, {39,41}, {43,45}, {33,34}, {35,36}, {37,38}, {39,40}, {41,42},
+    {43,44}, {45,46}, {36,40}, {38,42}, {34,36}, {38,40}, {42,44}, {37,41}, {39,43}, {35,37}, {39,41}, {43,45},
+    {33,34}, {35,36}, {37,38}, {39,40}, {41,42}, {43,44}, {45,46}, {0,32}, {16,32}, {8,40}, {24,40}, {8,16},
+    {24,32}, {4,36}, {20,36}, {12,44}, {28,44}, {12,20}, {28,36}, {4,8}, {12,16}, {20,24}, {28,32}, {36,40},
+    {2,34}, {18,34}, {10,42}, {26,42}, {10,18}, {26,34}, {6,38}, {22,38}, {14,46}, {30,46}, {14,22}, {30,38},
+    {6,10}, {14,18}, {22,26}, {30,34}, {38,42}, {2,4}, {6,8}, {10,12}, {14,16}, {18,20}, {22,24}, {26,28},
+    {30,32}, {34,36}, {38,40}, {42,44}, {1,33}, {17,33}, {9,41}, {25,41}, {9,17}, {25,33}, {5,37}, {21,37},
+    {13,45}, {29,45}, {13,21}, {29,37}, {5,9}, {13,17}, {21,25}, {29,33}, {37,41}, {3,35}, {19,35}, {11,43},
+    {27,43}, {11,19}, {27,35}, {7,39}, {23,39}, {15,47}, {31,47}, {15,23}, {31,39}, {7,11}, {15,19}, {23,27},
+    {31,35}, {39,43}, {3,5}, {7,9}, {11,13}, {15,17}, {19,21}, {23,25}, {27,29}, {31,33}, {35,37}, {39,41},
+    {43,45}, {1,2}, {3,4}, {5,6}, {7,8}, {9,10}, {11,12}, {13,14}, {15,16}, {17,18}, {19,20}, {21,22},
+    {23,24}, {25,26}, {27,28}, {29,30}, {31,32}, {33,34}, {35,36}, {37,38}, {39,40}, {41,42}, {43,44}, {45,46},
+};
 __device__ __forceinline__ void cswap(float &a, float &b)
 {
     const float lo = __builtin_fminf(a, b);   // v_min_f32 / v_max_f32; -0 orders before +0, which
@@ -121,26 +143,16 @@ __device__ __forceinline__ void cswap(float &a, float &b)
     a = lo;
     b = hi;
 }
-__device__ __forceinline__ void bitonic_sort64(float (&v)[64])
+__device__ __forceinline__ void sort48(float (&v)[kCsSlots])
 {
 #pragma unroll
-    for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int i = 0; i < 64; ++i) {
-                const int l = i ^ j;
-                if (l > i) {
-                    if ((i & k) == 0) cswap(v[i], v[l]);
-                    else cswap(v[l], v[i]);
-                }
-            }
+    for (int k = 0; k < 384; ++k) cswap(v[kSort48[k].a], v[kSort48[k].b]);
 }
 
 // Data step (:1733-1758) + non-local divergence (:1056-1079) + ofnltv_getP (:1090-1120) + relaxation.
 // The data step needs the element of index n+1 (0-based; `it/2+1` with it = 2n+1, sic) of the
 // ascending sort of  A = { -(b_s - r) : valid s }  united with  B = { (n-2j)*l_t*sg : j = 0..n }.
-// A is sorted in registers (padding = +inf); B is an arithmetic progression, so the order statistic
+// A is sorted in registers (invalid slots = +inf); B is an arithmetic progression, so the order statistic
 // is  min over i of max(A_sorted[i-1], B_ascending[n+1-i])  -- the classic two-sorted-arrays split.
 // DATA_L1 = true: the data step is TV-L1's thresholding (nltvl1_PD, :1246-1272) on rho_c.
 template <bool DATA_L1>
@@ -160,7 +172,10 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
         const float ixw = base[N_I1WX * pe + i], iyw = base[N_I1WY * pe + i];
         const float sg = __builtin_sqrtf(grad);
         const float r = (ixw * u1k + iyw * u2k) / sg;
-        float A[64];
+        const float *I0 = base + N_I0 * pe, *I1w = base + N_I1W * pe;
+        const float i0 = I0[i], i1w = I1w[i], t1 = base[N_T1 * pe + i], t2 = base[N_T2 * pe + i];
+        const double rsg = recip_f64(sg);                       // sg >= 1e-4: 48 exact quotients share it
+        float A[kCsSlots];
         int n = 0, s = 0;
 #pragma unroll
         for (int k = -kCsR; k <= kCsR; ++k)
@@ -168,14 +183,13 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
             for (int l = -kCsR; l <= kCsR; ++l) {
                 if (k == 0 && l == 0) continue;
                 const bool valid = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
-                const float bs = base[(size_t)(N_B + s) * pe + i];
+                const int pos = valid ? i + k * nx + l : i;
+                const float bs = div_by(i0 - I0[pos] - i1w + I1w[pos] + t1 + t2, sg, rsg);   // :1716-1717
                 A[s] = valid ? -(bs - r) : __builtin_inff();            // :1741-1742
                 n += valid ? 1 : 0;
                 ++s;
             }
-#pragma unroll
-        for (int t = kCsSlots; t < 64; ++t) A[t] = __builtin_inff();
-        bitonic_sort64(A);
+        sort48(A);
         float m = __builtin_inff();
 #pragma unroll
         for (int c = 1; c <= kCsSlots; ++c) {                            // c elements taken from A, n+2-c from B

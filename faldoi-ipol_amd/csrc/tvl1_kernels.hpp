@@ -175,6 +175,13 @@ __global__ void selftest_division_kernel(unsigned seed, unsigned long long count
         bad += m2;
         bad_sub += m2 && (fabsf(t_ref) < 1.17549435e-38f);
     }
+    // exhaustive: sqrt(g*g) == |g| for every float the fast path of sqrt_of_square accepts
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < (1ull << 32);
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float g = __uint_as_float((unsigned)i);
+        if (sqrt_of_square_is_abs(g))
+            bad += (__float_as_uint(__builtin_sqrtf(g * g)) != __float_as_uint(__builtin_fabsf(g)));
+    }
     // exhaustive: sqrt_ge1 against sqrtf for every float in [1, FLT_MAX] (and +inf)
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
          i <= 0x7f800000ull - 0x3f800000ull; i += (unsigned long long)gridDim.x * blockDim.x) {
