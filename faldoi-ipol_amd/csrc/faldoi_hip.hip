@@ -670,7 +670,7 @@ static int preprocess_device(faldoi_ctx *c, float *A, float *B, float *C, float 
     const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
     hipStream_t s = c->stream;
     hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, s, A, B, C, n, part + 6);
-    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, s, part + 6, blocks, part);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, s, part + 6, blocks, part);
     hipLaunchKernelGGL(normalize3_kernel, dim3(blocks), dim3(256), 0, s, A, B, C, n, part);
     float *planes[3] = {A, B, C};
     for (int k = 0; k < 3; ++k) {                     // src/global_faldoi.cpp:2066-2068

@@ -59,16 +59,31 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const float *__rest
     if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(64) void minmax_final_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ out6)
+__global__ __launch_bounds__(256) void minmax_final_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ out6)
 {
-    if (threadIdx.x >= 6) return;
-    const bool is_max = threadIdx.x & 1;
-    float v = part[threadIdx.x];
-    for (int b = 1; b < nblocks; ++b) {
-        const float w = part[b * 6 + threadIdx.x];
-        v = is_max ? (w > v ? w : v) : (w < v ? w : v);
+    __shared__ float s[6][256];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const bool is_max = k & 1;
+        float v = part[k];
+        for (int b = threadIdx.x; b < nblocks; b += 256) {
+            const float w = part[b * 6 + k];
+            v = is_max ? (w > v ? w : v) : (w < v ? w : v);
+        }
+        s[k][threadIdx.x] = v;
     }
-    out6[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float a = s[k][threadIdx.x], w = s[k][threadIdx.x + st];
+                s[k][threadIdx.x] = (k & 1) ? (w > a ? w : a) : (w < a ? w : a);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out6[threadIdx.x] = s[threadIdx.x][0];
 }
 
 // src/utils.cpp:743-781 image_normalization_3, in place on the three planes.
