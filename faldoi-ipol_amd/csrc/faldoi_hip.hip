@@ -171,19 +171,33 @@ struct TileCfg {
     int R, NW;           // rows per thread, waves per workgroup (tile = 64 x R*NW)
 };
 
-static TileCfg pick_tile()
+static bool tile_supported(int r, int w)
 {
-    TileCfg t{4, 16};
-    if (const char *s = getenv("FALDOI_TILE")) {     // tuning aid: "R,NW"
+    return (r == 4 && (w == 16 || w == 12 || w == 8)) || (r == 3 && (w == 16 || w == 12)) || (r == 8 && w == 8) ||
+           (r == 2 && w == 16);
+}
+
+// Tile shape and iterations per launch.  Measured on MI355X (tools/sweep.py, 1024x436 pairs):
+//   * while the 64x64 / k=10 tiling yields at most one tile per CU (a single pair of this size:
+//     240 tiles on 256 CUs) it is the fastest -- fewest launches, all CUs busy once;
+//   * with more tiles than CUs (batches, large frames) occupancy is no longer the constraint and
+//     the halo redundancy is: 64x36 tiles advanced 5 iterations per launch computed 1.5x instead of
+//     2.2x the useful pixels and ran 16-27 % faster (2-8 pairs per GPU).
+// An explicit params.chunk or FALDOI_TILE=R,NW (tuning aid) overrides the choice.
+static void pick_schedule(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, TileCfg *tc, int *chunk)
+{
+    const int S = kTileW - 20;                                  // owned pixels per 64-wide tile at k = 10
+    const long tiles_big = (long)((b->nx + S - 1) / S) * ((b->ny + S - 1) / S) * b->npairs;
+    const bool small_job = tiles_big <= b->ctx->n_cu;
+    *tc = small_job ? TileCfg{4, 16} : TileCfg{3, 12};
+    int k = prm->chunk ? prm->chunk : (small_job ? 10 : 5);
+    if (const char *s = getenv("FALDOI_TILE")) {
         int r = 0, w = 0;
-        if (sscanf(s, "%d,%d", &r, &w) == 2) {
-            if ((r == 4 && (w == 16 || w == 14 || w == 12 || w == 11 || w == 10 || w == 8)) ||
-                (r == 3 && (w == 16 || w == 14 || w == 12)) || (r == 8 && w == 8) || (r == 6 && w == 8) ||
-                (r == 2 && w == 16))
-                t = TileCfg{r, w};
-        }
+        if (sscanf(s, "%d,%d", &r, &w) == 2 && tile_supported(r, w)) *tc = TileCfg{r, w};
     }
-    return t;
+    if (k > prm->max_inner) k = prm->max_inner;
+    while (k > 1 && tc->R * tc->NW - 2 * k < 8) --k;            // keep a useful tile interior
+    *chunk = k;
 }
 
 template <int R, int NW>
@@ -341,11 +355,10 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
     faldoi_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const TileCfg tc = pick_tile();
+    TileCfg tc;
+    int chunk;
+    pick_schedule(b, prm, &tc, &chunk);
     const int TH = tc.R * tc.NW;
-    int chunk = prm->chunk ? prm->chunk : 10;
-    if (chunk > prm->max_inner) chunk = prm->max_inner;
-    while (chunk > 1 && TH - 2 * chunk < 8) --chunk;       // keep a useful tile interior
     const int halo = chunk;
     const int Sx = kTileW - 2 * halo, Sy = TH - 2 * halo;
     const int ntx = (b->nx + Sx - 1) / Sx, nty = (b->ny + Sy - 1) / Sy;
