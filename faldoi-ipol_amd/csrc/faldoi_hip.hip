@@ -173,8 +173,8 @@ struct TileCfg {
 
 static bool tile_supported(int r, int w)
 {
-    return (r == 4 && (w == 16 || w == 12 || w == 8)) || (r == 3 && (w == 16 || w == 12)) || (r == 8 && w == 8) ||
-           (r == 2 && w == 16);
+    return (r == 4 && (w == 16 || w == 12 || w == 8)) || (r == 3 && (w == 16 || w == 12 || w == 8)) ||
+           (r == 8 && w == 8) || (r == 2 && w == 16);
 }
 
 // Tile shape and iterations per launch.  Measured on MI355X (tools/sweep.py, 1024x436 pairs):
@@ -219,17 +219,13 @@ static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base
         return launch_chunk_t<r, w>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, first, \
                                     iters, slot);
     FALDOI_CASE(4, 16)
-    FALDOI_CASE(4, 14)
-    FALDOI_CASE(4, 12)
-    FALDOI_CASE(4, 11)
-    FALDOI_CASE(4, 10)
-    FALDOI_CASE(4, 8)
-    FALDOI_CASE(3, 16)
-    FALDOI_CASE(3, 14)
     FALDOI_CASE(3, 12)
-    FALDOI_CASE(8, 8)
-    FALDOI_CASE(6, 8)
+    FALDOI_CASE(4, 12)
+    FALDOI_CASE(3, 16)
+    FALDOI_CASE(4, 8)
+    FALDOI_CASE(3, 8)
     FALDOI_CASE(2, 16)
+    FALDOI_CASE(8, 8)
 #undef FALDOI_CASE
     return hipErrorInvalidValue;
 }
