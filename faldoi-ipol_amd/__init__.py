@@ -9,4 +9,4 @@ The directory name follows the upstream project and is not a Python identifier; 
 `faldoi_ipol_amd` (the loader shim faldoi_ipol_amd.py at the repository root does that).
 """
 from . import batch, build, capi, flo, shard  # noqa: F401
-from .capi import Context, FaldoiError, Tvl1Batch, default_params  # noqa: F401
+from .capi import Context, FaldoiError, LocalTvl1, Tvl1Batch, default_params  # noqa: F401

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libfaldoi_hip.so")
 SOURCES = [os.path.join(HERE, "csrc", "faldoi_hip.hip")]
 DEPS = SOURCES + [os.path.join(HERE, "csrc", f) for f in ("faldoi_device.hpp", "tvl1_kernels.hpp",
-                                                          "preprocess_kernels.hpp", "nltv_kernels.hpp")] + [
+                                                          "preprocess_kernels.hpp", "nltv_kernels.hpp", "local_kernels.hpp")] + [
     os.path.join(ROOT, "include", "faldoi_hip.h")]
 BIN = os.path.join(HERE, "bin")
 HOST = os.path.join(HERE, "host")

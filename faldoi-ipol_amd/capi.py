@@ -27,6 +27,8 @@ EXPORTS = [
     "faldoi_nltvcsad_default_params", "faldoi_nltvcsad_global", "faldoi_image_to_lab",
     "faldoi_nltvl1_default_params", "faldoi_nltvl1_global",
     "faldoi_zoom_size", "faldoi_zoom_out", "faldoi_zoom_in",
+    "faldoi_local_tvl1_create", "faldoi_local_tvl1_destroy", "faldoi_local_tvl1_set_flow",
+    "faldoi_local_tvl1_get_flow", "faldoi_local_tvl1_estimate",
 ]
 
 
@@ -109,6 +111,13 @@ def lib():
     L.faldoi_zoom_size.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.faldoi_zoom_out.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.c_float]
     L.faldoi_zoom_in.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.faldoi_local_tvl1_create.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.POINTER(vp)]
+    L.faldoi_local_tvl1_destroy.argtypes = [vp]
+    L.faldoi_local_tvl1_destroy.restype = None
+    L.faldoi_local_tvl1_set_flow.argtypes = [vp, _F]
+    L.faldoi_local_tvl1_get_flow.argtypes = [vp, _F]
+    L.faldoi_local_tvl1_estimate.argtypes = [vp, C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"),
+                                             C.c_int, _F, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
     L.faldoi_selftest_division.argtypes = [vp, C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
@@ -319,3 +328,42 @@ def image_to_lab(rgb):
     out = np.empty_like(rgb)
     _check(lib().faldoi_image_to_lab(rgb, rgb.shape[2], rgb.shape[1], out))
     return out
+
+
+class LocalTvl1:
+    """The local TV-l2 coupled patch operator (faldoi_local_tvl1): device-resident flow, duals, divergence."""
+
+    def __init__(self, ctx, i0n, i1n):
+        i0n, i1n = _f32(i0n), _f32(i1n)
+        self.h, self.w = i0n.shape
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        _check(lib().faldoi_local_tvl1_create(ctx._h, i0n, i1n, self.w, self.h, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().faldoi_local_tvl1_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_flow(self, u):
+        _check(lib().faldoi_local_tvl1_set_flow(self._h, _f32(u)))
+
+    def get_flow(self):
+        u = np.empty((2, self.h, self.w), np.float32)
+        _check(lib().faldoi_local_tvl1_get_flow(self._h, u))
+        return u
+
+    def estimate(self, patches, max_iter_patch=4):
+        """patches: (n,4) int32 rows {ii, ij, ei, ej}.  Returns (energies[n], iterations[n])."""
+        patches = np.ascontiguousarray(np.asarray(patches, np.int32).reshape(-1, 4))
+        n = len(patches)
+        ener = np.empty(n, np.float32)
+        iters = np.empty(n, np.int32)
+        _check(lib().faldoi_local_tvl1_estimate(self._h, n, patches, int(max_iter_patch), ener, iters))
+        return ener, iters

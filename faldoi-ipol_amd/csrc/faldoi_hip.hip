@@ -7,6 +7,7 @@
 #include "tvl1_kernels.hpp"
 #include "preprocess_kernels.hpp"
 #include "nltv_kernels.hpp"
+#include "local_kernels.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -940,6 +941,120 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (solve_ms) *solve_ms = ms;
     if (prm->verbose) fprintf(stderr, "NLTV (%s data term): %d warps x %d iterations, %.3f ms on the device\n", data_l1 ? "L1" : "CSAD", prm->warps, prm->max_inner, ms);
+    return FALDOI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ local patch operator
+struct faldoi_local_tvl1 {
+    faldoi_ctx *ctx = nullptr;
+    int nx = 0, ny = 0;
+    size_t pe = 0;
+    float *planes = nullptr;          // [L_COUNT][pe]
+    PatchDesc *d_patches = nullptr;
+    float *d_ener = nullptr;
+    int *d_iters = nullptr;
+    int cap = 0;
+};
+
+extern "C" void faldoi_local_tvl1_destroy(faldoi_local_tvl1 *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    if (h->planes) (void)hipFree(h->planes);
+    if (h->d_patches) (void)hipFree(h->d_patches);
+    if (h->d_ener) (void)hipFree(h->d_ener);
+    if (h->d_iters) (void)hipFree(h->d_iters);
+    delete h;
+}
+
+extern "C" int faldoi_local_tvl1_create(faldoi_ctx *ctx, const float *I0, const float *I1, int nx, int ny,
+                                        faldoi_local_tvl1 **out)
+{
+    if (!ctx || !I0 || !I1 || !out) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    int rc = prim_check(ctx, nx, ny);
+    if (rc) return rc;
+    faldoi_local_tvl1 *h = new (std::nothrow) faldoi_local_tvl1;
+    if (!h) return fail(FALDOI_ERR_OOM, "host allocation failed");
+    h->ctx = ctx; h->nx = nx; h->ny = ny;
+    const size_t n = (size_t)nx * ny;
+    h->pe = ((n + 63) / 64) * 64;
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMalloc((void **)&h->planes, sizeof(float) * h->pe * L_COUNT);
+    if (e == hipSuccess) e = hipMemsetAsync(h->planes, 0, sizeof(float) * h->pe * L_COUNT, s);   // duals, div, flow start at 0
+    if (e == hipSuccess) e = hipMemcpyAsync(h->planes + L_I0 * h->pe, I0, sizeof(float) * n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->planes + L_I1 * h->pe, I1, sizeof(float) * n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        // prepare_stuff (src/energy_model.cpp:660-686): centred gradient of the target frame
+        hipLaunchKernelGGL(centered_gradient_kernel, dim3(blocks), dim3(256), 0, s, h->planes + L_I1 * h->pe,
+                           h->planes + L_I1X * h->pe, h->planes + L_I1Y * h->pe, nx, ny, (size_t)0, (size_t)0, 1);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        faldoi_local_tvl1_destroy(h);
+        return fail(e == hipErrorOutOfMemory ? FALDOI_ERR_OOM : FALDOI_ERR_HIP, "local context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_local_tvl1_set_flow(faldoi_local_tvl1 *h, const float *u)
+{
+    if (!h || !u) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    const size_t n = (size_t)h->nx * h->ny;
+    HIP_TRY(hipMemcpyAsync(h->planes + L_U1 * h->pe, u, sizeof(float) * n, hipMemcpyHostToDevice, h->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h->planes + L_U2 * h->pe, u + n, sizeof(float) * n, hipMemcpyHostToDevice, h->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_local_tvl1_get_flow(faldoi_local_tvl1 *h, float *u)
+{
+    if (!h || !u) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    const size_t n = (size_t)h->nx * h->ny;
+    HIP_TRY(hipMemcpyAsync(u, h->planes + L_U1 * h->pe, sizeof(float) * n, hipMemcpyDeviceToHost, h->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(u + n, h->planes + L_U2 * h->pe, sizeof(float) * n, hipMemcpyDeviceToHost, h->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
+                                          float *ener_out, int *iters_out)
+{
+    if (!h || !patches || !ener_out) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    if (npatches < 1 || npatches > (1 << 20)) return fail(FALDOI_ERR_INVALID, "npatches=%d outside 1..2^20", npatches);
+    if (max_iter_patch < 0 || max_iter_patch > 100000) return fail(FALDOI_ERR_INVALID, "bad max_iter_patch");
+    for (int i = 0; i < npatches; ++i) {
+        const int ii = patches[4 * i], ij = patches[4 * i + 1], ei = patches[4 * i + 2], ej = patches[4 * i + 3];
+        if (ii < 0 || ij < 0 || ei > h->nx || ej > h->ny || ei - ii < 2 || ej - ij < 2 || ei - ii > kPatchMax ||
+            ej - ij > kPatchMax)
+            return fail(FALDOI_ERR_INVALID, "patch %d [%d,%d)x[%d,%d) outside the image or not 2..%d wide/high", i, ii, ei, ij,
+                        ej, kPatchMax);
+    }
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    if (h->cap < npatches) {
+        if (h->d_patches) (void)hipFree(h->d_patches);
+        if (h->d_ener) (void)hipFree(h->d_ener);
+        if (h->d_iters) (void)hipFree(h->d_iters);
+        h->d_patches = nullptr; h->d_ener = nullptr; h->d_iters = nullptr; h->cap = 0;
+        HIP_TRY(hipMalloc((void **)&h->d_patches, sizeof(PatchDesc) * npatches));
+        HIP_TRY(hipMalloc((void **)&h->d_ener, sizeof(float) * npatches));
+        HIP_TRY(hipMalloc((void **)&h->d_iters, sizeof(int) * npatches));
+        h->cap = npatches;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_patches, patches, sizeof(PatchDesc) * npatches, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(local_tvl1_patch_kernel, dim3(npatches), dim3(kPatchThreads), 0, s, h->planes, h->pe, h->nx, h->ny,
+                       h->d_patches, max_iter_patch, h->d_ener, h->d_iters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ener_out, h->d_ener, sizeof(float) * npatches, hipMemcpyDeviceToHost, s));
+    if (iters_out) HIP_TRY(hipMemcpyAsync(iters_out, h->d_iters, sizeof(int) * npatches, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return FALDOI_OK;
 }
 

@@ -48,6 +48,7 @@ enum {
 
 typedef struct faldoi_ctx faldoi_ctx;
 typedef struct faldoi_tvl1_batch faldoi_tvl1_batch;
+typedef struct faldoi_local_tvl1 faldoi_local_tvl1;
 
 /* Solver parameters: the scalar arguments of tvl2OF (src/global_faldoi.cpp:565-572) plus the
  * two knobs the reference hard-codes (loop bound MAX_ITERATIONS_GLOBAL and the tolerance stop,
@@ -150,6 +151,31 @@ int faldoi_preprocess_global(faldoi_ctx *ctx, const float *i0, const float *i1, 
  * initial flow u (2 planes) and duals xi (4 planes or NULL = zero), as faldoi_tvl1_batch_upload. */
 int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
                                     const float *im1, int pd, const float *u, const float *xi);
+
+/* ---------------------------------------------------------------- local patch operator (TV-l2 coupled)
+ * The operator local_faldoi calls ~3 M times per pair:
+ *   initialize_auxiliar_stuff + prepare_stuff   src/energy_model.cpp:202,276   -> faldoi_local_tvl1_create
+ *   of_estimation(ofS, ofD, &ener, i0, i1, i_1, index, w, h)   src/energy_model.cpp:691 (default branch:
+ *     guided_tvl2coupled src/tvl2_model.cpp:249 + eval_tvl2coupled :174)     -> faldoi_local_tvl1_estimate
+ *   free_auxiliar_stuff                         src/energy_model.cpp:240       -> faldoi_local_tvl1_destroy
+ * I0, I1: the planes prepare_stuff produces (gray, 2-image normalisation, Gaussian 0.9); the centred
+ * gradient of I1 is computed here.  The flow (OpticalFlowData::u1|u2) lives on the device between
+ * calls: set_flow / get_flow move all of it.  A patch is get_index_patch's window
+ * {ii, ij, ei, ej} (src/utils.cpp:36), 2..11 pixels wide and high; parameters are the ones
+ * of_estimation hard-wires (lambda 40, theta 0.3, tau 0.125, tol 0.01, 1 warp).
+ * Like the reference operator this one is STATEFUL: duals and both divergence planes persist between
+ * calls, and divergence_patch's behaviour of leaving the window's first row / first and last column
+ * stale while writing the image's row 0 / columns 0 and nx-1 (src/utils.cpp:88-103) is kept, so a
+ * sequence of single-patch calls reproduces the reference bit for bit.  Several patches in one call
+ * run concurrently; that equals the sequential order only if their windows (and those writes) do not
+ * interact.  ener_out[npatches] = *ener_N; iters_out may be NULL. */
+int faldoi_local_tvl1_create(faldoi_ctx *ctx, const float *I0, const float *I1, int nx, int ny,
+                             faldoi_local_tvl1 **out);
+void faldoi_local_tvl1_destroy(faldoi_local_tvl1 *h);
+int faldoi_local_tvl1_set_flow(faldoi_local_tvl1 *h, const float *u);
+int faldoi_local_tvl1_get_flow(faldoi_local_tvl1 *h, float *u);
+int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
+                               float *ener_out, int *iters_out);
 
 /* ---------------------------------------------------------------- pyramid resampling
  * src/zoom.c:19-106 (zoom_size, zoom_out, zoom_in).  The reference never compiles or calls

@@ -1,0 +1,159 @@
+/*
+ * faldoi_oracle_local.c -- CPU restatement of the LOCAL TV-L1 patch operator:
+ * of_estimation's default branch (src/energy_model.cpp:796-800) = guided_tvl2coupled
+ * (src/tvl2_model.cpp:249-435) followed by eval_tvl2coupled (:174-243), on one patch window
+ * [ii,ei) x [ij,ej) of full-size planes, with the patch stencils forward_gradient_patch
+ * (src/utils.cpp:175-220) and divergence_patch (src/utils.cpp:63-113).
+ *
+ * TEST INFRASTRUCTURE ONLY (see faldoi_oracle.h).
+ *
+ * The operator is stateful in the reference: its scratch planes (Tvl2CoupledOFStuff) live as long
+ * as the growing runs, and divergence_patch does not write the patch's own first row and first /
+ * last column (it writes the IMAGE's row 0, column 0 and column nx-1 instead), so
+ * those entries of div keep whatever an earlier call left there.  The state is therefore explicit
+ * here: `st` = 6 persistent planes (xi11, xi12, xi21, xi22, div1, div2), zero at creation.
+ */
+#include "faldoi_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* src/utils.cpp:175-220: zero fx on the PATCH's last column, fy on its last row */
+static void fwd_grad_patch(const float *f, float *fx, float *fy, int ii, int ij, int ei, int ej, int nx)
+{
+    for (int j = ij; j < ej; j++)
+        for (int i = ii; i < ei; i++) {
+            const int p = j * nx + i;
+            fx[p] = (i < ei - 1) ? f[p + 1] - f[p] : 0.0f;
+            fy[p] = (j < ej - 1) ? f[p + nx] - f[p] : 0.0f;
+        }
+}
+
+/* src/utils.cpp:63-113, statement by statement (order matters where targets coincide) */
+static void div_patch(const float *v1, const float *v2, float *div, int ii, int ij, int ei, int ej, int nx)
+{
+    for (int j = ij + 1; j < ej - 1; j++)                                   /* :76-86 body */
+        for (int i = ii + 1; i < ei - 1; i++) {
+            const int p = j * nx + i;
+            div[p] = (v1[p] - v1[p - 1]) + (v2[p] - v2[p - nx]);
+        }
+    for (int i = ii + 1; i < ei - 1; i++) {                                 /* :88-93: IMAGE row 0, patch last row */
+        const int p = (ej - 1) * nx + i;
+        div[i] = v1[i] - v1[i - 1] + v2[i];
+        div[p] = v1[p] - v1[p - 1] - v2[p - nx];
+    }
+    for (int j = ij + 1; j < ej - 1; j++) {                                 /* :96-103: IMAGE columns 0 and nx-1 */
+        const int p1 = j * nx;
+        const int p2 = (j + 1) * nx - 1;
+        div[p1] = v1[p1] + v2[p1] - v2[p1 - nx];
+        div[p2] = -v1[p2 - 1] + v2[p2] - v2[p2 - nx];
+    }
+    div[ij * nx + ii] = v1[ij * nx + ii] + v2[ij * nx + ii];               /* :104-108 the four patch corners */
+    div[ij * nx + ei - 1] = -v1[ij * nx + ei - 2] + v2[ij * nx + ei - 1];
+    div[(ej - 1) * nx + ii] = v1[(ej - 1) * nx + ii] - v2[(ej - 2) * nx + ii];
+    div[(ej - 1) * nx + ei - 1] = -v1[(ej - 1) * nx + ei - 2] - v2[(ej - 2) * nx + ei - 1];
+}
+
+/* One call of of_estimation (TV-l2 coupled).  I1x/I1y = centred gradient of I1 (prepare_stuff).
+ * u1,u2: full planes, updated inside the window.  st: 6*nx*ny persistent floats.  Returns the
+ * patch energy (*ener_N of the reference); *iters_out = inner iterations run. */
+float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x, const float *I1y,
+                              float *u1, float *u2, float *st, int nx, int ny,
+                              int ii, int ij, int ei, int ej, int max_iter_patch, int *iters_out)
+{
+    const float lambda = 40, theta = 0.3f, tau = 0.125f, tol_OF = 0.01f;   /* src/energy_model.cpp:704-709 */
+    const float l_t = lambda * theta;
+    const size_t n = (size_t)nx * ny;
+    float *xi11 = st, *xi12 = st + n, *xi21 = st + 2 * n, *xi22 = st + 3 * n, *div1 = st + 4 * n, *div2 = st + 5 * n;
+    float *w = (float *)calloc(n * 13, sizeof(float));
+    float *I1w = w, *I1wx = w + n, *I1wy = w + 2 * n, *grad = w + 3 * n, *rho_c = w + 4 * n, *ub1 = w + 5 * n,
+          *ub2 = w + 6 * n, *v1 = w + 7 * n, *v2 = w + 8 * n, *u1x = w + 9 * n, *u1y = w + 10 * n, *u2x = w + 11 * n,
+          *u2y = w + 12 * n;
+
+    for (int l = ij; l < ej; l++)                                          /* :313-321 */
+        for (int k = ii; k < ei; k++) {
+            const int i = l * nx + k;
+            xi11[i] = xi12[i] = xi21[i] = xi22[i] = 0.0f;
+        }
+    for (int l = ij; l < ej; l++)                                          /* :325-355, warps = 1 */
+        for (int k = ii; k < ei; k++) {
+            const int i = l * nx + k;
+            const float uu = (float)k + u1[i], vv = (float)l + u2[i];
+            I1w[i] = orc_bicubic_at(I1, uu, vv, nx, ny, 0);
+            I1wx[i] = orc_bicubic_at(I1x, uu, vv, nx, ny, 0);
+            I1wy[i] = orc_bicubic_at(I1y, uu, vv, nx, ny, 0);
+            const float Ix2 = I1wx[i] * I1wx[i], Iy2 = I1wy[i] * I1wy[i];
+            grad[i] = Ix2 + Iy2;
+            rho_c[i] = I1w[i] - I1wx[i] * u1[i] - I1wy[i] * u2[i] - I0[i];
+            ub1[i] = u1[i];
+            ub2[i] = u2[i];
+        }
+
+    int it = 0;
+    float err_D = INFINITY;
+    while (err_D > tol_OF * tol_OF && it < max_iter_patch) {               /* :359 */
+        it++;
+        for (int l = ij; l < ej; l++)                                      /* :364-391 */
+            for (int k = ii; k < ei; k++) {
+                const int i = l * nx + k;
+                const float rho = rho_c[i] + (I1wx[i] * u1[i] + I1wy[i] * u2[i]);
+                float d1, d2;
+                if (rho < -l_t * grad[i]) { d1 = l_t * I1wx[i]; d2 = l_t * I1wy[i]; }
+                else if (rho > l_t * grad[i]) { d1 = -l_t * I1wx[i]; d2 = -l_t * I1wy[i]; }
+                else if (grad[i] < 1E-8) { d1 = d2 = 0; }
+                else { const float fi = -rho / grad[i]; d1 = fi * I1wx[i]; d2 = fi * I1wy[i]; }
+                v1[i] = u1[i] + d1;
+                v2[i] = u2[i] + d2;
+            }
+        fwd_grad_patch(ub1, u1x, u1y, ii, ij, ei, ej, nx);                 /* :396-397 */
+        fwd_grad_patch(ub2, u2x, u2y, ii, ij, ei, ej, nx);
+        for (int l = ij; l < ej; l++)                                      /* tvl2coupled_getD :82-115 */
+            for (int k = ii; k < ei; k++) {
+                const int i = l * nx + k;
+                const float g11 = xi11[i] * xi11[i], g12 = xi12[i] * xi12[i], g21 = xi21[i] * xi21[i],
+                            g22 = xi22[i] * xi22[i];
+                float xi_N = sqrtf(g11 + g12 + g21 + g22);
+                xi_N = (1 > xi_N) ? 1 : xi_N;
+                xi11[i] = (xi11[i] + tau * u1x[i]) / xi_N;
+                xi12[i] = (xi12[i] + tau * u1y[i]) / xi_N;
+                xi21[i] = (xi21[i] + tau * u2x[i]) / xi_N;
+                xi22[i] = (xi22[i] + tau * u2y[i]) / xi_N;
+            }
+        div_patch(xi11, xi12, div1, ii, ij, ei, ej, nx);                   /* :401-402 */
+        div_patch(xi21, xi22, div2, ii, ij, ei, ej, nx);
+        err_D = 0;                                                          /* tvl2coupled_getP :122-166 */
+        for (int l = ij; l < ej; l++)
+            for (int k = ii; k < ei; k++) {
+                const int i = l * nx + k;
+                const float u1k = u1[i], u2k = u2[i];
+                u1[i] = u1k - tau * (-div1[i] + (u1k - v1[i]) / theta);
+                u2[i] = u2k - tau * (-div2[i] + (u2k - v2[i]) / theta);
+                const float uN = (u1[i] - u1k) * (u1[i] - u1k) + (u2[i] - u2k) * (u2[i] - u2k);
+                if (err_D < uN) err_D = uN;
+                ub1[i] = 2 * u1[i] - u1k;                                  /* :420-427 */
+                ub2[i] = 2 * u2[i] - u2k;
+            }
+    }
+    if (iters_out) *iters_out = it;
+
+    /* eval_tvl2coupled :174-243 (v1, v2 of the last iteration; gradients and warp of the NEW flow) */
+    fwd_grad_patch(u1, u1x, u1y, ii, ij, ei, ej, nx);
+    fwd_grad_patch(u2, u2x, u2y, ii, ij, ei, ej, nx);
+    float ener = 0.0f;
+    int m = 0;
+    for (int l = ij; l < ej; l++)
+        for (int k = ii; k < ei; k++) {
+            const int i = l * nx + k;
+            const float iw = orc_bicubic_at(I1, (float)k + u1[i], (float)l + u2[i], nx, ny, 0);
+            const float dt = lambda * fabsf(iw - I0[i]);
+            const float dc = (1 / (2 * theta)) * ((u1[i] - v1[i]) * (u1[i] - v1[i]) + (u2[i] - v2[i]) * (u2[i] - v2[i]));
+            const float g1 = u1x[i] * u1x[i], g12 = u1y[i] * u1y[i], g21 = u2x[i] * u2x[i], g2 = u2y[i] * u2y[i];
+            const float g = sqrtf(g1 + g12 + g21 + g2);
+            ener += dc + dt + g;
+            m++;
+        }
+    ener = (float)(ener / (m * 1.0));
+    free(w);
+    return ener;
+}

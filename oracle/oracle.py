@@ -18,7 +18,8 @@ def build(force=False):
     """Compile liboracle.so (and _ref when the reference sources are present)."""
     so = os.path.join(_HERE, "liboracle.so")
     import fcntl
-    srcs = [os.path.join(_HERE, f) for f in ("faldoi_oracle.c", "faldoi_oracle_nltv.c", "faldoi_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("faldoi_oracle.c", "faldoi_oracle_nltv.c", "faldoi_oracle_local.c",
+                                             "faldoi_oracle.h")]
     fd = os.open(os.path.join(_HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
     try:
         fcntl.flock(fd, fcntl.LOCK_EX)              # several ranks / xdist workers may get here together
@@ -92,6 +93,8 @@ def lib():
         L.orc_nltvcsad_global.argtypes = [_F, _F, _F, C.c_int, C.c_float, C.c_float, C.c_float,
                                           C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]
         L.orc_nltvl1_global.argtypes = L.orc_nltvcsad_global.argtypes
+        L.orc_local_tvl1_estimate.argtypes = [_F] * 7 + [C.c_int] * 7 + [C.POINTER(C.c_int)]
+        L.orc_local_tvl1_estimate.restype = C.c_float
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads(cpu_share())      # libgomp may already be loaded (torch) with its own default
@@ -116,6 +119,14 @@ def ref():
         R.ref_bicubic_at.argtypes = [_F, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         R.ref_bicubic_at.restype = C.c_float
         R.ref_bicubic_warp.argtypes = [_F, _F, _F, _F, C.c_int, C.c_int, C.c_int]
+        if hasattr(R, "ref_local_tvl1_create"):
+            R.ref_local_tvl1_create.argtypes = [C.c_int, C.c_int]
+            R.ref_local_tvl1_create.restype = C.c_void_p
+            R.ref_local_tvl1_destroy.argtypes = [C.c_void_p]
+            R.ref_local_tvl1_estimate.argtypes = [C.c_void_p, _F, _F, _F, _F, _F, _F] + [C.c_int] * 5
+            R.ref_local_tvl1_estimate.restype = C.c_float
+            R.ref_local_tvl1_div.argtypes = [C.c_void_p, C.c_int]
+            R.ref_local_tvl1_div.restype = C.POINTER(C.c_float)
         if hasattr(R, "ref_zoom_out"):
             R.ref_zoom_size.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_float]
             R.ref_zoom_out.argtypes = [_F, _F, C.c_int, C.c_int, C.c_float]
@@ -209,3 +220,26 @@ def zoom_in(img, ww, hh):
     out = np.empty((hh, ww), np.float32)
     lib().orc_zoom_in(img, out, w, h, ww, hh)
     return out
+
+
+def patch_index(wr, w, h, i, j):
+    """get_index_patch (src/utils.cpp:36-54, factor 1): clipped (2wr+1)^2 window -> (ii, ij, ei, ej)."""
+    return max(i - wr, 0), max(j - wr, 0), min(i + 1 + wr, w), min(j + 1 + wr, h)
+
+
+class LocalTvl1:
+    """Stateful local TV-L1 patch operator (oracle side): persistent xi/div planes, zero at creation."""
+
+    def __init__(self, i0n, i1n):
+        self.i0, self.i1 = f32(i0n), f32(i1n)
+        self.h, self.w = self.i0.shape
+        self.i1x, self.i1y = centered_gradient(self.i1)
+        self.state = np.zeros((6, self.h, self.w), np.float32)
+
+    def estimate(self, u, patch, max_iter_patch=4):
+        """u: (2,h,w) float32, updated in place inside the patch.  Returns (energy, iterations)."""
+        it = C.c_int(0)
+        ii, ij, ei, ej = patch
+        e = lib().orc_local_tvl1_estimate(self.i0, self.i1, self.i1x, self.i1y, u[0], u[1], self.state,
+                                          self.w, self.h, ii, ij, ei, ej, max_iter_patch, C.byref(it))
+        return float(np.float32(e)), it.value

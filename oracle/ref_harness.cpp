@@ -5,7 +5,9 @@
 // /root/reference/src by oracle/Makefile, so ctypes can reach the C++-mangled symbols.
 // It exists to pin oracle/faldoi_oracle.c bit-for-bit against the reference primitives.
 // The outputs (oracle/_ref/) are git-ignored and are never shipped with the product.
+#include <cstring>
 #include "utils.h"                       // reference: src/utils.h
+#include "tvl2_model.h"                  // reference: src/tvl2_model.h (guided_tvl2coupled)
 extern "C" {
 #include "bicubic_interpolation.h"       // reference: src/bicubic_interpolation.h
 #include "zoom.h"                        // reference: src/zoom.h (zoom.c is compiled with mask.c, as it includes mask.h)
@@ -50,5 +52,58 @@ void ref_zoom_out(const float *I, float *Iout, int nx, int ny, float factor)
 
 void ref_zoom_in(const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
 { zoom_in(I, Iout, nx, ny, nxx, nyy); }                           // src/zoom.c:82
+
+// ---- the local TV-L1 patch operator: the reference's own guided_tvl2coupled (src/tvl2_model.cpp:249)
+// on the reference's own scratch structure, allocated by its initialize_stuff_tvl2coupled (:16) and
+// zero-filled here so that "what an earlier call left behind" is well defined.
+struct RefLocal {
+    SpecificOFStuff stuff;
+    OpticalFlowData ofd;
+    int w, h;
+};
+
+void *ref_local_tvl1_create(int w, int h)
+{
+    RefLocal *r = new RefLocal();
+    r->w = w; r->h = h;
+    memset(&r->ofd, 0, sizeof(OpticalFlowData));
+    initialize_stuff_tvl2coupled(&r->stuff, &r->ofd, w, h);
+    Tvl2CoupledOFStuff &t = r->stuff.tvl2;
+    float *planes[] = {t.xi11, t.xi12, t.xi21, t.xi22, t.u1x, t.u1y, t.u2x, t.u2y, t.v1, t.v2, t.rho_c, t.grad,
+                       t.u1_, t.u2_, t.u1Aux, t.u2Aux, t.I1x, t.I1y, t.I1w, t.I1wx, t.I1wy, t.div_xi1, t.div_xi2, t.u_N};
+    for (float *p : planes) memset(p, 0, sizeof(float) * (size_t)w * h);
+    return r;
+}
+
+void ref_local_tvl1_destroy(void *h)
+{
+    RefLocal *r = (RefLocal *)h;
+    free_stuff_tvl2coupled(&r->stuff);
+    delete r;
+}
+
+// One of_estimation call for the TV-l2 coupled functional with of_estimation's hard-wired parameters
+// (src/energy_model.cpp:704-709,796-800).  I1x/I1y are copied into the structure as prepare_stuff does.
+float ref_local_tvl1_estimate(void *h, const float *I0, const float *I1, const float *I1x, const float *I1y,
+                              float *u1, float *u2, int ii, int ij, int ei, int ej, int max_iter_patch)
+{
+    RefLocal *r = (RefLocal *)h;
+    const size_t n = (size_t)r->w * r->h;
+    memcpy(r->stuff.tvl2.I1x, I1x, sizeof(float) * n);
+    memcpy(r->stuff.tvl2.I1y, I1y, sizeof(float) * n);
+    r->ofd.u1 = u1;
+    r->ofd.u2 = u2;
+    r->ofd.params.max_iter_patch = max_iter_patch;
+    float ener = 0.f;
+    guided_tvl2coupled(I0, I1, &r->ofd, &r->stuff.tvl2, &ener, ii, ij, ei, ej, 40, 0.3, 0.125, 0.01, 1, false,
+                       r->w, r->h);
+    return ener;
+}
+
+const float *ref_local_tvl1_div(void *h, int which)
+{
+    RefLocal *r = (RefLocal *)h;
+    return which ? r->stuff.tvl2.div_xi2 : r->stuff.tvl2.div_xi1;
+}
 
 }  // extern "C"

@@ -413,3 +413,50 @@ def test_second_sintel_pair_large_motion(ctx, oracle):
     assert bits_equal(g0, o0) and bits_equal(g1, o1)
     u = _compare_solve(ctx, oracle, g0, g1, np.zeros((2, 436, 1024), np.float32))
     assert float(np.abs(u).max()) > 30.0
+
+
+# ------------------------------------------------------------------ local patch operator
+def test_local_patch_operator_sequence_bit_exact(ctx, oracle):
+    # one patch per call, overlapping windows, 3x3 and 11x11, image corners: the sequential use the
+    # reference makes of of_estimation.  Oracle (pinned to the reference objects) vs GPU: energies,
+    # iteration counts and the whole flow plane after every call.
+    i0, i1 = sintel_pair((400, 150, 96, 64))
+    i0n, i1n = oracle.preprocess_global(i0, i1)
+    h, w = i0n.shape
+    rng = np.random.default_rng(0)
+    u_o = (rng.standard_normal((2, h, w)) * 0.5).astype(np.float32)
+    op = oracle.LocalTvl1(i0n, i1n)
+    g = F.LocalTvl1(ctx, i0n, i1n)
+    g.set_flow(u_o)
+    centers = [(5, 5), (7, 6), (20, 30), (21, 30), (0, 0), (95, 63), (50, 1), (48, 3), (94, 30), (2, 40), (30, 30),
+               (30, 31), (60, 20)] * 2
+    for n, (ci, cj) in enumerate(centers):
+        pi = oracle.patch_index(1 if n % 5 == 0 else 5, w, h, ci, cj)
+        e_o, it_o = op.estimate(u_o, pi, 4)
+        e_g, it_g = g.estimate([pi], 4)
+        assert int(it_g[0]) == it_o, n
+        assert np.float32(e_o).view(np.uint32) == e_g.view(np.uint32)[0], (n, e_o, e_g)
+        assert bits_equal(g.get_flow(), u_o), n
+    g.close()
+
+
+def test_local_patch_operator_batch_of_disjoint_patches(ctx, oracle):
+    # many non-interacting windows in ONE launch == the same windows one after the other
+    i0n, i1n, gt = synthetic_pair(256, 160, seed=21)
+    rng = np.random.default_rng(5)
+    u0 = (gt + rng.standard_normal(gt.shape) * 0.4).astype(np.float32)
+    u_o = u0.copy()
+    op = oracle.LocalTvl1(i0n, i1n)
+    patches = [oracle.patch_index(5, 256, 160, ci, cj) for cj in range(20, 150, 24) for ci in range(20, 240, 24)]
+    e_o = [op.estimate(u_o, pi, 4) for pi in patches]
+    g = F.LocalTvl1(ctx, i0n, i1n)
+    g.set_flow(u0)
+    e_g, it_g = g.estimate(patches, 4)
+    assert [int(x) for x in it_g] == [it for _, it in e_o]
+    assert np.array_equal(e_g.view(np.uint32), np.array([e for e, _ in e_o], np.float32).view(np.uint32))
+    assert bits_equal(g.get_flow(), u_o)
+    with pytest.raises(F.FaldoiError):
+        g.estimate([(0, 0, 12, 5)], 4)            # wider than 11
+    with pytest.raises(F.FaldoiError):
+        g.estimate([(250, 0, 257, 5)], 4)         # outside the image
+    g.close()
