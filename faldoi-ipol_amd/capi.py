@@ -28,7 +28,8 @@ EXPORTS = [
     "faldoi_nltvl1_default_params", "faldoi_nltvl1_global",
     "faldoi_zoom_size", "faldoi_zoom_out", "faldoi_zoom_in",
     "faldoi_local_tvl1_create", "faldoi_local_tvl1_destroy", "faldoi_local_tvl1_set_flow",
-    "faldoi_local_tvl1_get_flow", "faldoi_local_tvl1_estimate",
+    "faldoi_local_tvl1_get_flow", "faldoi_local_tvl1_estimate", "faldoi_local_tvl1_set_fixed",
+    "faldoi_local_tvl1_interpolate",
 ]
 
 
@@ -118,6 +119,8 @@ def lib():
     L.faldoi_local_tvl1_get_flow.argtypes = [vp, _F]
     L.faldoi_local_tvl1_estimate.argtypes = [vp, C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"),
                                              C.c_int, _F, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
+    L.faldoi_local_tvl1_set_fixed.argtypes = [vp, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
+    L.faldoi_local_tvl1_interpolate.argtypes = [vp, C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
     L.faldoi_selftest_division.argtypes = [vp, C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
@@ -358,6 +361,13 @@ class LocalTvl1:
         u = np.empty((2, self.h, self.w), np.float32)
         _check(lib().faldoi_local_tvl1_get_flow(self._h, u))
         return u
+
+    def set_fixed(self, fixed):
+        _check(lib().faldoi_local_tvl1_set_fixed(self._h, np.ascontiguousarray(fixed, np.int32)))
+
+    def interpolate(self, patches):
+        patches = np.ascontiguousarray(np.asarray(patches, np.int32).reshape(-1, 4))
+        _check(lib().faldoi_local_tvl1_interpolate(self._h, len(patches), patches))
 
     def estimate(self, patches, max_iter_patch=4):
         """patches: (n,4) int32 rows {ii, ij, ei, ej}.  Returns (energies[n], iterations[n])."""

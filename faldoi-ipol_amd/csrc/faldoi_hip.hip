@@ -953,6 +953,7 @@ struct faldoi_local_tvl1 {
     PatchDesc *d_patches = nullptr;
     float *d_ener = nullptr;
     int *d_iters = nullptr;
+    int *d_fixed = nullptr;           // OpticalFlowData::fixed_points (1 = fixed), nx*ny
     int cap = 0;
 };
 
@@ -965,6 +966,7 @@ extern "C" void faldoi_local_tvl1_destroy(faldoi_local_tvl1 *h)
     if (h->d_patches) (void)hipFree(h->d_patches);
     if (h->d_ener) (void)hipFree(h->d_ener);
     if (h->d_iters) (void)hipFree(h->d_iters);
+    if (h->d_fixed) (void)hipFree(h->d_fixed);
     delete h;
 }
 
@@ -982,6 +984,8 @@ extern "C" int faldoi_local_tvl1_create(faldoi_ctx *ctx, const float *I0, const 
     h->pe = ((n + 63) / 64) * 64;
     hipStream_t s = ctx->stream;
     hipError_t e = hipMalloc((void **)&h->planes, sizeof(float) * h->pe * L_COUNT);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_fixed, sizeof(int) * n);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_fixed, 0, sizeof(int) * n, s);
     if (e == hipSuccess) e = hipMemsetAsync(h->planes, 0, sizeof(float) * h->pe * L_COUNT, s);   // duals, div, flow start at 0
     if (e == hipSuccess) e = hipMemcpyAsync(h->planes + L_I0 * h->pe, I0, sizeof(float) * n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(h->planes + L_I1 * h->pe, I1, sizeof(float) * n, hipMemcpyHostToDevice, s);
@@ -1023,12 +1027,9 @@ extern "C" int faldoi_local_tvl1_get_flow(faldoi_local_tvl1 *h, float *u)
     return FALDOI_OK;
 }
 
-extern "C" int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
-                                          float *ener_out, int *iters_out)
+static int local_patches_to_device(faldoi_local_tvl1 *h, int npatches, const int *patches)
 {
-    if (!h || !patches || !ener_out) return fail(FALDOI_ERR_INVALID, "NULL argument");
     if (npatches < 1 || npatches > (1 << 20)) return fail(FALDOI_ERR_INVALID, "npatches=%d outside 1..2^20", npatches);
-    if (max_iter_patch < 0 || max_iter_patch > 100000) return fail(FALDOI_ERR_INVALID, "bad max_iter_patch");
     for (int i = 0; i < npatches; ++i) {
         const int ii = patches[4 * i], ij = patches[4 * i + 1], ei = patches[4 * i + 2], ej = patches[4 * i + 3];
         if (ii < 0 || ij < 0 || ei > h->nx || ej > h->ny || ei - ii < 2 || ej - ij < 2 || ei - ii > kPatchMax ||
@@ -1037,7 +1038,6 @@ extern "C" int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, co
                         ej, kPatchMax);
     }
     HIP_TRY(hipSetDevice(h->ctx->device));
-    hipStream_t s = h->ctx->stream;
     if (h->cap < npatches) {
         if (h->d_patches) (void)hipFree(h->d_patches);
         if (h->d_ener) (void)hipFree(h->d_ener);
@@ -1048,7 +1048,40 @@ extern "C" int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, co
         HIP_TRY(hipMalloc((void **)&h->d_iters, sizeof(int) * npatches));
         h->cap = npatches;
     }
-    HIP_TRY(hipMemcpyAsync(h->d_patches, patches, sizeof(PatchDesc) * npatches, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_patches, patches, sizeof(PatchDesc) * npatches, hipMemcpyHostToDevice, h->ctx->stream));
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_local_tvl1_set_fixed(faldoi_local_tvl1 *h, const int *fixed_points)
+{
+    if (!h || !fixed_points) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    HIP_TRY(hipMemcpyAsync(h->d_fixed, fixed_points, sizeof(int) * (size_t)h->nx * h->ny, hipMemcpyHostToDevice, h->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_local_tvl1_interpolate(faldoi_local_tvl1 *h, int npatches, const int *patches)
+{
+    if (!h || !patches) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    int rc = local_patches_to_device(h, npatches, patches);
+    if (rc) return rc;
+    hipStream_t s = h->ctx->stream;
+    hipLaunchKernelGGL(interpolate_poisson_kernel, dim3((2 * npatches + 63) / 64), dim3(64), 0, s, h->planes, h->pe, h->nx,
+                       h->d_fixed, h->d_patches, npatches);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
+                                          float *ener_out, int *iters_out)
+{
+    if (!h || !patches || !ener_out) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    if (max_iter_patch < 0 || max_iter_patch > 100000) return fail(FALDOI_ERR_INVALID, "bad max_iter_patch");
+    int rc = local_patches_to_device(h, npatches, patches);
+    if (rc) return rc;
+    hipStream_t s = h->ctx->stream;
     hipLaunchKernelGGL(local_tvl1_patch_kernel, dim3(npatches), dim3(kPatchThreads), 0, s, h->planes, h->pe, h->nx, h->ny,
                        h->d_patches, max_iter_patch, h->d_ener, h->d_iters);
     HIP_TRY(hipGetLastError());

@@ -174,4 +174,94 @@ __global__ __launch_bounds__(kPatchThreads) void local_tvl1_patch_kernel(float *
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// interpolate_poisson (src/local_faldoi.cpp:326-372) = elap_recursive_separable(out, in, w, h, 2,
+// 0.4, 3, 7) (src/elap_recsep.c:193-231) on a window: the non-fixed pixels become holes that are
+// filled by a multiscale harmonic extension; every window pixel is written back.
+// The relaxation of the reference is sequential (each update sees the neighbours already updated in
+// the same sweep, src/elap_recsep.c:50-69), so one thread owns one (window, flow channel) and runs
+// it in order; the parallelism is across windows.  The recursion is unrolled into a pyramid built
+// top-down and solved bottom-up.
+// ---------------------------------------------------------------------------------------------
+constexpr int kElapLevels = 7;                   // `scale` of the call site
+constexpr int kElapPix = kPatchMax * kPatchMax;  // 121
+constexpr int kElapPyr = 121 + 36 + 9 + 4 + 1 + 1 + 1;   // 11 -> 6 -> 3 -> 2 -> 1 -> 1 -> 1
+
+__device__ __forceinline__ float px_clamp(const float *x, int w, int h, int i, int j)     // getpixel_1 :24-31
+{
+    i = i < 0 ? 0 : (i >= w ? w - 1 : i);
+    j = j < 0 ? 0 : (j >= h ? h - 1 : j);
+    return x[i + j * w];
+}
+
+__global__ __launch_bounds__(64) void interpolate_poisson_kernel(float *__restrict__ base, size_t pe, int nx,
+                                                               const int *__restrict__ fixed_points,
+                                                               const PatchDesc *__restrict__ patches, int npatches)
+{
+    const int job = blockIdx.x * 64 + threadIdx.x;
+    if (job >= 2 * npatches) return;
+    const PatchDesc pd = patches[job >> 1];
+    float *U = base + (size_t)((job & 1) ? L_U2 : L_U1) * pe;
+    const int w0 = pd.ei - pd.ii, h0 = pd.ej - pd.ij;
+    float in[kElapPyr], out[kElapPyr], init[kElapPix];
+    int ws[kElapLevels], hs[kElapLevels], off[kElapLevels];
+    ws[0] = w0; hs[0] = h0; off[0] = 0;
+    for (int s = 1; s < kElapLevels; ++s) {                         // ceil(w/2.0), :195-196
+        ws[s] = (ws[s - 1] + 1) / 2;
+        hs[s] = (hs[s - 1] + 1) / 2;
+        off[s] = off[s - 1] + ws[s - 1] * hs[s - 1];
+    }
+    for (int j = 0; j < h0; ++j)                                    // src/local_faldoi.cpp:341-355
+        for (int i = 0; i < w0; ++i) {
+            const int xy = (j + pd.ij) * nx + i + pd.ii;
+            in[j * w0 + i] = (fixed_points[xy] == 1) ? U[xy] : __builtin_nanf("");
+        }
+    for (int s = 1; s < kElapLevels; ++s) {                         // zoom_out_by_factor_two :160-175
+        const float *src = in + off[s - 1];
+        float *dst = in + off[s];
+        const int iw = ws[s - 1], ih = hs[s - 1];
+        for (int j = 0; j < hs[s]; ++j)
+            for (int i = 0; i < ws[s]; ++i) {
+                const float a[4] = { px_clamp(src, iw, ih, 2 * i, 2 * j), px_clamp(src, iw, ih, 2 * i + 1, 2 * j),
+                                     px_clamp(src, iw, ih, 2 * i, 2 * j + 1), px_clamp(src, iw, ih, 2 * i + 1, 2 * j + 1) };
+                float m = 0;
+                int cx = 0;
+                for (int q = 0; q < 4; ++q)
+                    if (__builtin_isfinite(a[q])) { m += a[q]; cx += 1; }
+                dst[ws[s] * j + i] = cx ? m / cx : __builtin_nanf("");
+            }
+    }
+    for (int s = kElapLevels - 1; s >= 0; --s) {
+        const int w = ws[s], h = hs[s];
+        const float *x = in + off[s];
+        float *y = out + off[s];
+        for (int j = 0; j < h; ++j)
+            for (int i = 0; i < w; ++i) {
+                float iv = 0.0f;                                    // coarsest level starts from zero, :204-206
+                if (s < kElapLevels - 1)                            // zoom_in_by_factor_two :181-189
+                    iv = px_clamp(out + off[s + 1], ws[s + 1], hs[s + 1], (int)__builtin_round((i - 0.5) / 2),
+                                  (int)__builtin_round((j - 0.5) / 2));
+                init[j * w + i] = iv;
+            }
+        for (int q = 0; q < w * h; ++q) y[q] = __builtin_isfinite(x[q]) ? x[q] : init[q];      // :113-114
+        for (int it = 0; it < 3; ++it) {                            // niter = 3, tstep = 0.4
+            float maxupdate = 0;
+            for (int j = 0; j < h; ++j)
+                for (int i = 0; i < w; ++i) {
+                    if (!__builtin_isnan(x[j * w + i])) continue;
+                    const int idx = j * w + i;
+                    const float lap = -4 * px_clamp(y, w, h, i, j) + px_clamp(y, w, h, i + 1, j) + px_clamp(y, w, h, i, j + 1)
+                                      + px_clamp(y, w, h, i - 1, j) + px_clamp(y, w, h, i, j - 1);
+                    const float nw = y[idx] + 0.4f * lap;
+                    const float update = __builtin_fabsf(y[idx] - nw);
+                    if (update > maxupdate) maxupdate = update;
+                    y[idx] = nw;
+                }
+            if ((double)maxupdate < 1e-10) break;
+        }
+    }
+    for (int j = 0; j < h0; ++j)                                    // src/local_faldoi.cpp:359-368
+        for (int i = 0; i < w0; ++i) U[(j + pd.ij) * nx + i + pd.ii] = out[j * w0 + i];
+}
+
 }  // namespace faldoi

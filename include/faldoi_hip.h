@@ -176,6 +176,14 @@ int faldoi_local_tvl1_set_flow(faldoi_local_tvl1 *h, const float *u);
 int faldoi_local_tvl1_get_flow(faldoi_local_tvl1 *h, float *u);
 int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
                                float *ener_out, int *iters_out);
+/* interpolate_poisson(ofD, patch, w), src/local_faldoi.cpp:326-372, = elap_recursive_separable(out, in,
+ * w, h, 2, 0.4, 3, 7), src/elap_recsep.c:193-231: inside each window the pixels whose fixed_points
+ * entry is not 1 are replaced by a multiscale harmonic extension of the fixed ones (every window
+ * pixel is rewritten).  fixed_points: OpticalFlowData::fixed_points, nx*ny ints, uploaded by set_fixed.
+ * The relaxation is sequential in the reference, so each (window, channel) runs on one thread, in the
+ * reference's order; windows of one call run concurrently (same caveat as estimate). */
+int faldoi_local_tvl1_set_fixed(faldoi_local_tvl1 *h, const int *fixed_points);
+int faldoi_local_tvl1_interpolate(faldoi_local_tvl1 *h, int npatches, const int *patches);
 
 /* ---------------------------------------------------------------- pyramid resampling
  * src/zoom.c:19-106 (zoom_size, zoom_out, zoom_in).  The reference never compiles or calls

@@ -90,6 +90,10 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
                               float *u1, float *u2, float *state6, int nx, int ny,
                               int ii, int ij, int ei, int ej, int max_iter_patch, int *iters_out);
 
+/* src/elap_recsep.c:193-231 and interpolate_poisson, src/local_faldoi.cpp:326-372 */
+void orc_elap_recursive(float *out, const float *in, int w, int h, float timestep, int niter, int scale);
+void orc_interpolate_poisson(float *u1, float *u2, const int *fixed_points, int nx, int ii, int ij, int ei, int ej);
+
 void orc_nltvl1_global(const float *I0, const float *I1, const float *lab, int pd,
                        float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
                        float *u1, float *u2);

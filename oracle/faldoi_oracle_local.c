@@ -157,3 +157,109 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
     free(w);
     return ener;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Harmonic (Laplace) hole filling of a patch, src/elap_recsep.c:21-231, as interpolate_poisson
+ * (src/local_faldoi.cpp:326-372) calls it: elap_recursive_separable(out, in, w, h, pd, 0.4, 3, 7).
+ * Restated without recursion: a pyramid of up to `scale` levels is built top-down by 2x2 NaN-aware
+ * block means, solved from the coarsest level (zero initialisation) upwards, each level started
+ * from the pixel-replicated coarser solution.  The relaxation is sequential (Gauss-Seidel in mask
+ * order): every update sees the neighbours already updated in the same sweep.
+ * ---------------------------------------------------------------------------------------- */
+#define ELAP_MAXPIX 2500           /* MAX_PATCH*MAX_PATCH, src/parameters.h:89 */
+
+static float px_clamp(const float *x, int w, int h, int i, int j)      /* getpixel_1 :24-31 */
+{
+    if (i < 0) i = 0;
+    if (j < 0) j = 0;
+    if (i >= w) i = w - 1;
+    if (j >= h) j = h - 1;
+    return x[i + j * w];
+}
+
+static void harmonic_fill(float *y, const float *x, int w, int h, float tstep, int niter, const float *init)
+{
+    for (int i = 0; i < w * h; i++) y[i] = isfinite(x[i]) ? x[i] : init[i];        /* :113-114 */
+    for (int it = 0; it < niter; it++) {                                            /* :117-126 */
+        float maxupdate = 0;
+        for (int j = 0; j < h; j++)                                                 /* mask order = row-major (:78-84) */
+            for (int i = 0; i < w; i++) {
+                if (!isnan(x[j * w + i])) continue;
+                const int idx = j * w + i;
+                const float lap = -4 * px_clamp(y, w, h, i, j) + px_clamp(y, w, h, i + 1, j) + px_clamp(y, w, h, i, j + 1)
+                                  + px_clamp(y, w, h, i - 1, j) + px_clamp(y, w, h, i, j - 1);     /* :37-43 */
+                const float nw = y[idx] + tstep * lap;
+                const float update = (float)fabs(y[idx] - nw);
+                if (update > maxupdate) maxupdate = update;
+                y[idx] = nw;
+            }
+        if (maxupdate < 1e-10) break;
+    }
+}
+
+void orc_elap_recursive(float *out, const float *in, int w, int h, float timestep, int niter, int scale)
+{
+    enum { MAXL = 16 };
+    int ws[MAXL], hs[MAXL];
+    float *ins[MAXL], *outs[MAXL];
+    if (scale > MAXL) scale = MAXL;
+    ws[0] = w; hs[0] = h;
+    ins[0] = (float *)in;
+    for (int s = 1; s < scale; s++) {                                               /* :195-201 */
+        ws[s] = (int)ceil(ws[s - 1] / 2.0);
+        hs[s] = (int)ceil(hs[s - 1] / 2.0);
+        ins[s] = (float *)malloc(sizeof(float) * ws[s] * hs[s]);
+        const float *src = ins[s - 1];
+        const int iw = ws[s - 1], ih = hs[s - 1];
+        for (int j = 0; j < hs[s]; j++)                                             /* zoom_out_by_factor_two :160-175 */
+            for (int i = 0; i < ws[s]; i++) {
+                const float a[4] = { px_clamp(src, iw, ih, 2 * i, 2 * j), px_clamp(src, iw, ih, 2 * i + 1, 2 * j),
+                                     px_clamp(src, iw, ih, 2 * i, 2 * j + 1), px_clamp(src, iw, ih, 2 * i + 1, 2 * j + 1) };
+                float m = 0;
+                int cx = 0;
+                for (int k = 0; k < 4; k++)
+                    if (isfinite(a[k])) { m += a[k]; cx += 1; }
+                ins[s][ws[s] * j + i] = cx ? m / cx : NAN;
+            }
+    }
+    for (int s = scale - 1; s >= 0; s--) {
+        const int n = ws[s] * hs[s];
+        float *init = (float *)malloc(sizeof(float) * n);
+        outs[s] = (s == 0) ? out : (float *)malloc(sizeof(float) * n);
+        if (s == scale - 1) {
+            for (int i = 0; i < n; i++) init[i] = 0;                                /* :204-206 */
+        } else {                                                                    /* zoom_in_by_factor_two :181-189 */
+            for (int j = 0; j < hs[s]; j++)
+                for (int i = 0; i < ws[s]; i++)
+                    init[ws[s] * j + i] = px_clamp(outs[s + 1], ws[s + 1], hs[s + 1], (int)round((i - 0.5) / 2),
+                                                   (int)round((j - 0.5) / 2));
+        }
+        harmonic_fill(outs[s], ins[s], ws[s], hs[s], timestep, niter, init);        /* :208 */
+        free(init);
+    }
+    for (int s = 1; s < scale; s++) { free(ins[s]); free(outs[s]); }
+}
+
+/* interpolate_poisson (src/local_faldoi.cpp:326-372): non-fixed pixels of the window become holes,
+ * both flow channels are filled, ALL window pixels are written back. */
+void orc_interpolate_poisson(float *u1, float *u2, const int *fixed_points, int nx,
+                             int ii, int ij, int ei, int ej)
+{
+    const int w = ei - ii, h = ej - ij;
+    float bin[2][ELAP_MAXPIX], bout[2][ELAP_MAXPIX];
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            const int xy = (j + ij) * nx + i + ii;
+            const int fx = fixed_points[xy] == 1;
+            bin[0][j * w + i] = fx ? u1[xy] : NAN;
+            bin[1][j * w + i] = fx ? u2[xy] : NAN;
+        }
+    orc_elap_recursive(bout[0], bin[0], w, h, 0.4f, 3, 7);                          /* :357 */
+    orc_elap_recursive(bout[1], bin[1], w, h, 0.4f, 3, 7);
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            const int xy = (j + ij) * nx + i + ii;
+            u1[xy] = bout[0][j * w + i];
+            u2[xy] = bout[1][j * w + i];
+        }
+}

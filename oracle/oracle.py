@@ -93,6 +93,8 @@ def lib():
         L.orc_nltvcsad_global.argtypes = [_F, _F, _F, C.c_int, C.c_float, C.c_float, C.c_float,
                                           C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]
         L.orc_nltvl1_global.argtypes = L.orc_nltvcsad_global.argtypes
+        L.orc_elap_recursive.argtypes = [_F, _F, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
+        L.orc_interpolate_poisson.argtypes = [_F, _F, _I, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_local_tvl1_estimate.argtypes = [_F] * 7 + [C.c_int] * 7 + [C.POINTER(C.c_int)]
         L.orc_local_tvl1_estimate.restype = C.c_float
         L.orc_num_threads.restype = C.c_int
@@ -127,6 +129,8 @@ def ref():
             R.ref_local_tvl1_estimate.restype = C.c_float
             R.ref_local_tvl1_div.argtypes = [C.c_void_p, C.c_int]
             R.ref_local_tvl1_div.restype = C.POINTER(C.c_float)
+        if hasattr(R, "ref_elap_recursive_separable"):
+            R.ref_elap_recursive_separable.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
         if hasattr(R, "ref_zoom_out"):
             R.ref_zoom_size.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_float]
             R.ref_zoom_out.argtypes = [_F, _F, C.c_int, C.c_int, C.c_float]

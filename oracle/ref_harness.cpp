@@ -11,6 +11,7 @@
 extern "C" {
 #include "bicubic_interpolation.h"       // reference: src/bicubic_interpolation.h
 #include "zoom.h"                        // reference: src/zoom.h (zoom.c is compiled with mask.c, as it includes mask.h)
+#include "elap_recsep.h"                 // reference: src/elap_recsep.h
 }
 
 extern "C" {
@@ -52,6 +53,9 @@ void ref_zoom_out(const float *I, float *Iout, int nx, int ny, float factor)
 
 void ref_zoom_in(const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
 { zoom_in(I, Iout, nx, ny, nxx, nyy); }                           // src/zoom.c:82
+
+void ref_elap_recursive_separable(float *out, float *in, int w, int h, int pd, float timestep, int niter, int scale)
+{ elap_recursive_separable(out, in, w, h, pd, timestep, niter, scale); }     // src/elap_recsep.c:225
 
 // ---- the local TV-L1 patch operator: the reference's own guided_tvl2coupled (src/tvl2_model.cpp:249)
 // on the reference's own scratch structure, allocated by its initialize_stuff_tvl2coupled (:16) and

@@ -460,3 +460,26 @@ def test_local_patch_operator_batch_of_disjoint_patches(ctx, oracle):
     with pytest.raises(F.FaldoiError):
         g.estimate([(250, 0, 257, 5)], 4)         # outside the image
     g.close()
+
+
+def test_interpolate_poisson_bit_exact(ctx, oracle):
+    # interpolate_poisson on windows with random fixed / free pixels (incl. none fixed, all fixed, corners)
+    h, w = 48, 64
+    rng = np.random.default_rng(8)
+    i0n, i1n, _ = synthetic_pair(w, h, seed=2)
+    u = (rng.standard_normal((2, h, w)) * 2).astype(np.float32)
+    fixed = (rng.random((h, w)) < 0.35).astype(np.int32)
+    fixed[20:31, 40:51] = 0            # a window with no fixed pixel at all
+    fixed[0:11, 0:11] = 1              # and one with every pixel fixed
+    patches = [oracle.patch_index(5, w, h, ci, cj) for ci, cj in ((5, 5), (45, 25), (63, 47), (0, 47), (30, 10), (12, 40))]
+    patches.append(oracle.patch_index(1, w, h, 33, 33))
+    g = F.LocalTvl1(ctx, i0n, i1n)
+    u_o = u.copy()
+    g.set_flow(u)
+    g.set_fixed(fixed)
+    L = oracle.lib()
+    for pi in patches:                  # overlapping windows: one call each, like the reference
+        L.orc_interpolate_poisson(u_o[0], u_o[1], fixed, w, pi[0], pi[1], pi[2], pi[3])
+        g.interpolate([pi])
+        assert bits_equal(g.get_flow(), u_o), pi
+    g.close()
