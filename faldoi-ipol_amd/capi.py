@@ -30,6 +30,8 @@ EXPORTS = [
     "faldoi_local_tvl1_create", "faldoi_local_tvl1_destroy", "faldoi_local_tvl1_set_flow",
     "faldoi_local_tvl1_get_flow", "faldoi_local_tvl1_estimate", "faldoi_local_tvl1_set_fixed",
     "faldoi_local_tvl1_interpolate",
+    "faldoi_local_default_params", "faldoi_preprocess_local", "faldoi_match_growing_variational",
+    "faldoi_match_growing_batch",
 ]
 
 
@@ -48,6 +50,16 @@ class Tvl1Stats(C.Structure):
     _fields_ = [("total_iters", C.c_long), ("warps", C.c_int), ("iters_cap", C.c_int),
                 ("iters", C.POINTER(C.c_int)), ("err", C.POINTER(C.c_float)),
                 ("solve_ms", C.c_double), ("chunk_launches", C.c_int)]
+
+
+class LocalParams(C.Structure):
+    _fields_ = [("w_radio", C.c_int), ("iterations_of", C.c_int), ("max_iter_patch", C.c_int), ("epsilon", C.c_float),
+                ("preprocessed", C.c_int), ("budget", C.c_int), ("verbose", C.c_int)]
+
+
+class LocalStats(C.Structure):
+    _fields_ = [("pops", C.c_longlong * 2), ("solves", C.c_longlong * 2), ("fills", C.c_longlong * 2),
+                ("fb_kept", C.c_float * 16), ("growing_ms", C.c_float), ("launches", C.c_int)]
 
 
 class FaldoiError(RuntimeError):
@@ -122,6 +134,14 @@ def lib():
     L.faldoi_local_tvl1_set_fixed.argtypes = [vp, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
     L.faldoi_local_tvl1_interpolate.argtypes = [vp, C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
     L.faldoi_selftest_division.argtypes = [vp, C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
+    L.faldoi_local_default_params.argtypes = [C.POINTER(LocalParams)]
+    L.faldoi_local_default_params.restype = None
+    L.faldoi_preprocess_local.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.c_int, _F, _F]
+    L.faldoi_match_growing_variational.argtypes = [vp, _F, _F, _F, _F, vp, vp, C.c_int, C.c_int, C.c_int,
+                                                   C.POINTER(LocalParams), _F, _F, C.POINTER(LocalStats)]
+    pp = C.POINTER(C.c_void_p)
+    L.faldoi_match_growing_batch.argtypes = [vp, C.c_int, pp, pp, pp, pp, pp, pp, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(LocalParams), pp, pp, C.POINTER(LocalStats)]
     _lib = L
     return L
 
@@ -209,6 +229,55 @@ class Context:
         o0, o1 = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
         _check(lib().faldoi_preprocess_global(self._h, i0, i1, _ptr(im1), w, h, pd, o0, o1))
         return o0, o1
+
+    def preprocess_local(self, i0, i1):
+        """prepare_stuff's image part of the local step: (pd,h,w) or (h,w) frames -> normalised (h,w) pair."""
+        i0, i1 = _f32(i0), _f32(i1)
+        pd = 1 if i0.ndim == 2 else i0.shape[0]
+        h, w = i0.shape[-2:]
+        o0, o1 = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+        _check(lib().faldoi_preprocess_local(self._h, i0, i1, w, h, pd, o0, o1))
+        return o0, o1
+
+    @staticmethod
+    def _local_params(params):
+        p = LocalParams()
+        lib().faldoi_local_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, {"wr": "w_radio", "loc_it": "iterations_of", "fb_thresh": "epsilon"}.get(k, k), v)
+        return p
+
+    def match_growing(self, i0, i1, go, ba, sal0=None, sal1=None, **params):
+        """Mirror of match_growing_variational (-m 0, no partitions).  i0/i1: (pd,h,w) frames 0..255, or normalised
+        (h,w) planes with preprocessed=1.  go/ba: (2,h,w) seed flows, NaN = no seed.
+        Returns (out_flow (2,h,w), ene_val (h,w), LocalStats)."""
+        i0, i1, go, ba = _f32(i0), _f32(i1), _f32(go), _f32(ba)
+        pd = 1 if i0.ndim == 2 else i0.shape[0]
+        h, w = i0.shape[-2:]
+        sal0 = None if sal0 is None else _f32(sal0)
+        sal1 = None if sal1 is None else _f32(sal1)
+        out, ene, st = np.empty((2, h, w), np.float32), np.empty((h, w), np.float32), LocalStats()
+        p = self._local_params(params)
+        _check(lib().faldoi_match_growing_variational(self._h, go, ba, i0, i1, _ptr(sal0), _ptr(sal1), w, h, pd,
+                                                      C.byref(p), ene, out, C.byref(st)))
+        return out, ene, st
+
+    def match_growing_batch(self, i0s, i1s, gos, bas, **params):
+        """Several pairs of one size at once: lists of arrays as in match_growing.  Returns (flows, energies, stats)."""
+        k = len(i0s)
+        i0s, i1s, gos, bas = ([_f32(a) for a in x] for x in (i0s, i1s, gos, bas))
+        pd = 1 if i0s[0].ndim == 2 else i0s[0].shape[0]
+        h, w = i0s[0].shape[-2:]
+        outs = [np.empty((2, h, w), np.float32) for _ in range(k)]
+        enes = [np.empty((h, w), np.float32) for _ in range(k)]
+
+        def arr(xs):
+            return (C.c_void_p * k)(*[x.ctypes.data for x in xs])
+        st = LocalStats()
+        p = self._local_params(params)
+        _check(lib().faldoi_match_growing_batch(self._h, k, arr(gos), arr(bas), arr(i0s), arr(i1s), None, None, w, h, pd,
+                                                C.byref(p), arr(enes), arr(outs), C.byref(st)))
+        return outs, enes, st
 
     def _nl_global(self, defaults, solve, i0n, i1n, lab, u0, params):
         i0n, i1n, lab = _f32(i0n), _f32(i1n), _f32(lab)

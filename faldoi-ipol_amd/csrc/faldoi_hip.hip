@@ -8,6 +8,7 @@
 #include "preprocess_kernels.hpp"
 #include "nltv_kernels.hpp"
 #include "local_kernels.hpp"
+#include "grow_kernels.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -679,11 +680,13 @@ static int preprocess_device(faldoi_ctx *c, float *A, float *B, float *C, float 
     const int n = nx * ny;
     const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
     hipStream_t s = c->stream;
-    hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, s, A, B, C, n, part + 6);
+    // C == nullptr: the two-image form of the local step (image_normalization, src/utils.cpp:703)
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, s, A, B, C ? C : A, n, part + 6);
     hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, s, part + 6, blocks, part);
-    hipLaunchKernelGGL(normalize3_kernel, dim3(blocks), dim3(256), 0, s, A, B, C, n, part);
+    if (C) hipLaunchKernelGGL(normalize3_kernel, dim3(blocks), dim3(256), 0, s, A, B, C, n, part);
+    else hipLaunchKernelGGL(normalize2_kernel, dim3(blocks), dim3(256), 0, s, A, B, n, part);
     float *planes[3] = {A, B, C};
-    for (int k = 0; k < 3; ++k) {                     // src/global_faldoi.cpp:2066-2068
+    for (int k = 0; k < (C ? 3 : 2); ++k) {           // src/global_faldoi.cpp:2066-2068
         hipLaunchKernelGGL(gaussian_pass_kernel<false>, dim3(blocks), dim3(256), 0, s, planes[k], tmp, nx, ny, taps);
         hipLaunchKernelGGL(gaussian_pass_kernel<true>, dim3(blocks), dim3(256), 0, s, tmp, planes[k], nx, ny, taps);
     }
@@ -1201,3 +1204,5 @@ extern "C" int faldoi_bicubic_warp(faldoi_ctx *ctx, const float *in, const float
         hipLaunchKernelGGL(bicubic_warp_kernel, g, b, 0, s, i[0], i[1], i[2], o[0], nx, ny, border_out);
     });
 }
+
+#include "grow_host.inc"

@@ -107,6 +107,20 @@ __global__ void normalize3_kernel(float *__restrict__ A, float *__restrict__ B, 
     }
 }
 
+// image_normalization (src/utils.cpp:703-734), two images: the usual min of minima.
+__global__ void normalize2_kernel(float *__restrict__ A, float *__restrict__ B, int n, const float *__restrict__ mm)
+{
+    const float min0 = mm[0], max0 = mm[1], min1 = mm[2], max1 = mm[3];
+    const float mx = (max0 > max1) ? max0 : max1;
+    const float mn = (min0 < min1) ? min0 : min1;
+    const float den = mx - mn;
+    if (!(den > 0)) return;                              // reference copies the images unchanged
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        A[i] = (A[i] - mn) / den;
+        B[i] = (B[i] - mn) / den;
+    }
+}
+
 // Index held by the reference's padded line buffer at virtual position i (src/utils.cpp:566-571,
 // 600-605): left/top mirror WITHOUT repeating the edge sample, right/bottom mirror WITH it.
 __device__ __forceinline__ int reflect_index(int i, int n)

@@ -222,6 +222,45 @@ int faldoi_nltvl1_global(faldoi_ctx *ctx, const float *I0, const float *I1, cons
 /* src/global_faldoi.cpp:906-932 image_to_lab: planar R,G,B (0..255) -> planar L,a*,b* (host, libm). */
 int faldoi_image_to_lab(const float *rgb, int nx, int ny, float *lab);
 
+/* ---- the local step: match_growing_variational, src/local_faldoi.cpp:1060-1741 (-m 0, -split_img 0) ----
+ * Seeds -> priority-queue growing (forward and backward) -> forward-backward pruning -> re-seeding,
+ * `iterations_of` times, then a last forward growing.  Argument order follows the reference function:
+ * go / ba = seed flows (2 planes each, NaN = no seed), i0 / i1 = frames (planar, pd channels, 0..255; or
+ * already normalised gray planes when params->preprocessed), sal_* = saliency planes or NULL,
+ * ene_val (may be NULL) and out_flow (2 planes) = the forward energy map and flow.
+ * Every candidate is processed on the device in the reference's order (one workgroup per growing);
+ * the batch form runs the growings of several pairs of one size concurrently. */
+typedef struct faldoi_local_params {
+    int w_radio;          /* -wr,          PAR_DEFAULT_WINSIZE 5   (src/parameters.h:64) */
+    int iterations_of;    /* -loc_it,      LOCAL_ITER 3            (:61) */
+    int max_iter_patch;   /* -max_pch_it,  MAX_ITERATIONS_LOCAL 4  (:42) */
+    float epsilon;        /* -fb_thresh,   FB_TOL 2                (:63) */
+    int preprocessed;     /* extension: 1 = i0/i1 are normalised gray planes (skip prepare_stuff's image part) */
+    int budget;           /* windows per growing per kernel launch (host relaunches until the queue is empty) */
+    int verbose;
+} faldoi_local_params;
+typedef struct faldoi_local_stats {
+    long long pops[2];    /* candidates popped, forward / backward (summed over the batch) */
+    long long solves[2];  /* windows minimised (of_estimation calls) */
+    long long fills[2];   /* windows filled by interpolate_poisson */
+    float fb_kept[16];    /* "FB-Chosen" fraction per local iteration: [2*it] forward, [2*it+1] backward */
+    float growing_ms;     /* device time from the first seed to the last pop, incl. the host re-seeding */
+    int launches;
+} faldoi_local_stats;
+void faldoi_local_default_params(faldoi_local_params *p);
+/* prepare_stuff's image part for TV-l2 coupled (src/energy_model.cpp:660-684): gray, image_normalization
+ * over the two frames (src/utils.cpp:703-734), Gaussian 0.9. */
+int faldoi_preprocess_local(faldoi_ctx *ctx, const float *i0, const float *i1, int nx, int ny, int pd, float *i0n,
+                            float *i1n);
+int faldoi_match_growing_variational(faldoi_ctx *ctx, const float *go, const float *ba, const float *i0, const float *i1,
+                                     const float *sal_go, const float *sal_ba, int nx, int ny, int pd,
+                                     const faldoi_local_params *params, float *ene_val, float *out_flow,
+                                     faldoi_local_stats *stats);
+int faldoi_match_growing_batch(faldoi_ctx *ctx, int npairs, const float *const *go, const float *const *ba,
+                               const float *const *i0, const float *const *i1, const float *const *sal_go,
+                               const float *const *sal_ba, int nx, int ny, int pd, const faldoi_local_params *params,
+                               float *const *ene_val, float *const *out_flow, faldoi_local_stats *stats);
+
 /* ---------------------------------------------------------------- self-test
  * The kernels replace the IEEE fp32 divide on two call sites by an fp64-assisted sequence that
  * is proven to return the same bits (csrc/faldoi_device.hpp).  This entry point checks the claim

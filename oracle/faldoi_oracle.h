@@ -94,6 +94,17 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
 void orc_elap_recursive(float *out, const float *in, int w, int h, float timestep, int niter, int scale);
 void orc_interpolate_poisson(float *u1, float *u2, const int *fixed_points, int nx, int ii, int ij, int ei, int ej);
 
+/* ---- local step (faldoi_oracle_growing.cpp; src/local_faldoi.cpp:1060-1741, -m 0, no partitions) ---- */
+void orc_preprocess_local(const float *i0, const float *i1, int w, int h, int pd, float *i0n, float *i1n);
+void orc_local_faldoi(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,
+                      const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
+                      float *out_flow, float *ene_val, long *stats);
+double orc_fb_consistency_check(const float *in0, const float *in1, int *trust, int w, int h, float epsilon);
+void *orc_queue_new(void);
+void orc_queue_free(void *q);
+void orc_queue_push(void *q, int i, int j, float u, float v, float sim);
+int orc_queue_pop(void *q, int *i, int *j, float *u, float *v, float *sim);
+
 void orc_nltvl1_global(const float *I0, const float *I1, const float *lab, int pd,
                        float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
                        float *u1, float *u2);

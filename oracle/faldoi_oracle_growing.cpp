@@ -1,0 +1,285 @@
+// faldoi_oracle_growing.cpp -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of the local step of FALDOI: match_growing_variational
+// (src/local_faldoi.cpp:1060-1741) for the TV-l2 coupled functional (-m 0) without image
+// partitioning (-split_img 0) and without occlusions: seeds -> priority-queue growing
+// (forward and backward) -> forward-backward pruning -> re-seeding, `loc_it` times, then a last
+// forward growing.  The per-window operators (Poisson filling, of_estimation) are the C
+// restatements of faldoi_oracle_local.c, which are pinned bit-for-bit against the reference's own
+// objects.  The queue is std::priority_queue with the reference's comparator, i.e. exactly the
+// container the reference uses (src/energy_structures.h:13-30), so pop order (ties included) is
+// the reference's by construction.
+//
+// PARITY UNPINNED at this level: src/local_faldoi.cpp includes <boost/lexical_cast.hpp>, which
+// this image lacks, so the orchestration cannot be compiled from the reference here, and the
+// seed-dependent known answers of SURVEY App. D need the matcher binaries (not runnable here).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <queue>
+#include <vector>
+
+extern "C" {
+#include "faldoi_oracle.h"
+}
+
+namespace {
+
+struct Candidate {                 // SparseOF, src/energy_structures.h:13-20
+    int i, j;                      // column, row
+    float u, v, sim;
+};
+struct CandidateOrder {            // CompareSparseOF :22-27: smallest energy on top
+    bool operator()(const Candidate &a, const Candidate &b) const { return a.sim > b.sim; }
+};
+typedef std::priority_queue<Candidate, std::vector<Candidate>, CandidateOrder> CandidateQueue;
+
+struct Direction {                 // OpticalFlowData + Tvl2CoupledOFStuff + the per-direction arrays of :1082-1095
+    int w, h;
+    const float *src, *dst;        // normalised source / target frame (i0n,i1n forward; i1n,i0n backward)
+    const float *sal;              // saliency or NULL (= 1)
+    std::vector<float> dstx, dsty; // centred gradient of the target frame (prepare_stuff)
+    std::vector<float> u;          // ofD->u1 | u2
+    std::vector<float> state;      // xi11..xi22, div1, div2 (persistent, see faldoi_oracle_local.c)
+    std::vector<float> ene, out;   // ene_Go / oft0
+    std::vector<int> fixed, trust;
+    CandidateQueue queue;
+    long pops, solves, fills;
+    int max_iter_patch, wr;
+};
+
+struct Window { int ii, ij, ei, ej; };
+
+Window window_at(int wr, int w, int h, int i, int j)      // get_index_patch, src/utils.cpp:36-54
+{
+    Window x;
+    x.ii = (i - wr < 0) ? 0 : i - wr;
+    x.ij = (j - wr < 0) ? 0 : j - wr;
+    x.ei = (i + 1 + wr > w) ? w : i + 1 + wr;
+    x.ej = (j + 1 + wr > h) ? h : j + 1 + wr;
+    return x;
+}
+
+// add_neighbors, src/local_faldoi.cpp:679-727
+void add_neighbors(Direction &d, int i, int j, int iteration, int wr)
+{
+    const int w = d.w, h = d.h, n = w * h;
+    const Window x = window_at(wr, w, h, i, j);
+    float *u1 = d.u.data(), *u2 = u1 + n;
+    bool fill = (iteration == 0);
+    if (!fill)                                                           // check_trustable_patch :639-656
+        for (int l = x.ij; l < x.ej && !fill; l++)
+            for (int k = x.ii; k < x.ei; k++)
+                if (d.trust[l * w + k] == 0) { fill = true; break; }
+    if (fill) {
+        for (int l = x.ij; l < x.ej; l++)                                // copy_fixed_coordinates :609-628
+            for (int k = x.ii; k < x.ei; k++) {
+                const int p = l * w + k;
+                if (d.fixed[p] == 1) { u1[p] = d.out[p]; u2[p] = d.out[n + p]; }
+            }
+        orc_interpolate_poisson(u1, u2, d.fixed.data(), w, x.ii, x.ij, x.ei, x.ej);
+        d.fills++;
+    }
+    const float ener = orc_local_tvl1_estimate(d.src, d.dst, d.dstx.data(), d.dsty.data(), u1, u2, d.state.data(), w, h,
+                                               x.ii, x.ij, x.ei, x.ej, d.max_iter_patch, NULL);
+    d.solves++;
+    static const int nb[4][2] = { { 0, 1 }, { 0, -1 }, { 1, 0 }, { -1, 0 } };   // insert_candidates :497-537
+    for (int k = 0; k < 4; k++) {
+        const int px = i + nb[k][0], py = j + nb[k][1];
+        if (px < 0 || px >= w || py < 0 || py >= h) continue;
+        const int q = py * w + px;
+        const float new_ener = ener * (d.sal ? d.sal[q] : 1.0f);
+        if (!d.fixed[q] && new_ener < d.ene[q]) {
+            d.ene[q] = ener;
+            Candidate c = { px, py, u1[q], u2[q], new_ener };
+            d.queue.push(c);
+        }
+    }
+    const int p = j * w + i;                                             // :718-726
+    if (d.ene[p] > ener) {
+        d.out[p] = u1[p];
+        d.out[n + p] = u2[p];
+        d.ene[p] = ener;
+    }
+}
+
+void reset_growing(Direction &d)                                         // :755-761, :839-845, :860-870
+{
+    const int n = d.w * d.h;
+    for (int p = 0; p < n; p++) {
+        d.fixed[p] = 0;
+        d.ene[p] = INFINITY;
+        d.out[p] = d.out[n + p] = NAN;
+    }
+}
+
+// insert_initial_seeds, src/local_faldoi.cpp:748-796
+void insert_initial_seeds(Direction &d, const float *in_flow)
+{
+    const int w = d.w, h = d.h, n = w * h;
+    reset_growing(d);
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            const int p = j * w + i;
+            if (std::isfinite(in_flow[p]) && std::isfinite(in_flow[n + p])) {
+                d.out[p] = in_flow[p];
+                d.out[n + p] = in_flow[n + p];
+                d.fixed[p] = 1;
+                add_neighbors(d, i, j, 0, 1);                            // w_radio = 1 for the seeds, :764
+                d.out[p] = d.out[n + p] = NAN;
+                d.fixed[p] = 0;
+            }
+        }
+    for (int p = 0; p < n; p++)
+        if (std::isfinite(in_flow[p]) && std::isfinite(in_flow[n + p])) {
+            d.out[p] = in_flow[p];
+            d.out[n + p] = in_flow[n + p];
+            d.fixed[p] = 1;
+            d.ene[p] = 0.0f;
+        }
+}
+
+// local_growing, src/local_faldoi.cpp:891-1039 (without the partial-result dumps)
+void local_growing(Direction &d, int iteration)
+{
+    const int w = d.w, n = d.w * d.h;
+    while (!d.queue.empty()) {
+        const Candidate c = d.queue.top();
+        d.queue.pop();
+        d.pops++;
+        const int p = c.j * w + c.i;
+        if (d.fixed[p]) continue;
+        d.fixed[p] = 1;
+        d.out[p] = c.u;
+        d.out[n + p] = c.v;
+        d.ene[p] = c.sim;
+        add_neighbors(d, c.i, c.j, iteration, d.wr);
+    }
+}
+
+// fb_consistency_check, src/local_faldoi.cpp:167-190: |u(x) + v(x + u(x))| <= epsilon
+double fb_consistency_check(const float *in0, const float *in1, int *trust, int w, int h, float epsilon)
+{
+    const int n = w * h;
+    std::vector<float> u1w(n), u2w(n);
+    orc_bicubic_warp(in1, in0, in0 + n, u1w.data(), w, h, 1);
+    orc_bicubic_warp(in1 + n, in0, in0 + n, u2w.data(), w, h, 1);
+    long kept = 0;
+    for (int p = 0; p < n; p++) {
+        const float tolerance = hypotf(in0[p] + u1w[p], in0[n + p] + u2w[p]);
+        trust[p] = (tolerance > epsilon) ? 0 : 1;
+        kept += trust[p];
+    }
+    return (double)kept / n;
+}
+
+void delete_not_trustable_candidates(Direction &d)                       // :283-311
+{
+    const int n = d.w * d.h;
+    for (int p = 0; p < n; p++)
+        if (d.trust[p] == 0) {
+            d.out[p] = d.out[n + p] = NAN;
+            d.u[p] = d.u[n + p] = NAN;
+            d.ene[p] = INFINITY;
+        }
+}
+
+void insert_potential_candidates(Direction &d)                           // :813-846 (in == out_flow at the call site)
+{
+    const int w = d.w, h = d.h, n = w * h;
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            const int p = j * w + i;
+            if (std::isfinite(d.out[p]) && std::isfinite(d.out[n + p])) {
+                Candidate c = { i, j, d.out[p], d.out[n + p], d.ene[p] };
+                d.queue.push(c);
+            }
+        }
+    reset_growing(d);
+}
+
+void init_direction(Direction &d, const float *src, const float *dst, const float *sal, int w, int h, int wr,
+                    int max_iter_patch)
+{
+    const size_t n = (size_t)w * h;
+    d.w = w; d.h = h; d.src = src; d.dst = dst; d.sal = sal; d.wr = wr; d.max_iter_patch = max_iter_patch;
+    d.dstx.assign(n, 0.0f); d.dsty.assign(n, 0.0f);
+    orc_centered_gradient(dst, d.dstx.data(), d.dsty.data(), w, h);     // prepare_stuff, src/energy_model.cpp:660-684
+    d.u.assign(2 * n, 0.0f);       // `new float[]` in the reference (:186): fresh zero pages in practice, and
+                                   // every window is filled before it is first read
+    d.state.assign(6 * n, 0.0f);
+    d.ene.assign(n, 0.0f); d.out.assign(2 * n, 0.0f);
+    d.fixed.assign(n, 0); d.trust.assign(n, 1);
+    d.pops = d.solves = d.fills = 0;
+}
+
+}  // namespace
+
+// Hooks for unit tests of the device heap: the reference's container, driven step by step.
+extern "C" void *orc_queue_new(void) { return new CandidateQueue(); }
+extern "C" void orc_queue_free(void *q) { delete (CandidateQueue *)q; }
+extern "C" void orc_queue_push(void *q, int i, int j, float u, float v, float sim)
+{
+    Candidate c = { i, j, u, v, sim };
+    ((CandidateQueue *)q)->push(c);
+}
+extern "C" int orc_queue_pop(void *q, int *i, int *j, float *u, float *v, float *sim)
+{
+    CandidateQueue *pq = (CandidateQueue *)q;
+    if (pq->empty()) return 0;
+    const Candidate c = pq->top();
+    pq->pop();
+    *i = c.i; *j = c.j; *u = c.u; *v = c.v; *sim = c.sim;
+    return 1;
+}
+
+extern "C" double orc_fb_consistency_check(const float *in0, const float *in1, int *trust, int w, int h, float epsilon)
+{
+    return fb_consistency_check(in0, in1, trust, w, h, epsilon);
+}
+
+/* i0n, i1n: normalised frames (orc_preprocess_local).  go, ba: seed flows (2 planes, NaN = no seed).
+ * sal0, sal1: saliency planes or NULL.  out_flow (2 planes) and ene_val receive oft0 / ene_Go.
+ * stats (may be NULL): [0..2] forward pops / patch solves / Poisson fills, [3..5] backward. */
+extern "C" void orc_local_faldoi(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,
+                                 const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
+                                 float *out_flow, float *ene_val, long *stats)
+{
+    const size_t n = (size_t)w * h;
+    Direction d[2];
+    init_direction(d[0], i0n, i1n, sal0, w, h, wr, max_iter_patch);
+    init_direction(d[1], i1n, i0n, sal1, w, h, wr, max_iter_patch);
+#pragma omp parallel for num_threads(2)
+    for (int k = 0; k < 2; k++) insert_initial_seeds(d[k], k == 0 ? go : ba);     // :1130-1139
+    for (int it = 0; it < loc_it; it++) {                                          // :1184-1282
+#pragma omp parallel for num_threads(2)
+        for (int k = 0; k < 2; k++) local_growing(d[k], it);
+        fb_consistency_check(d[0].out.data(), d[1].out.data(), d[0].trust.data(), w, h, fb_thresh);   // pruning_method :209
+        fb_consistency_check(d[1].out.data(), d[0].out.data(), d[1].trust.data(), w, h, fb_thresh);
+        for (int k = 0; k < 2; k++) {
+            delete_not_trustable_candidates(d[k]);
+            insert_potential_candidates(d[k]);
+        }
+    }
+    local_growing(d[0], loc_it);                                                   // :1703
+    memcpy(out_flow, d[0].out.data(), sizeof(float) * 2 * n);
+    memcpy(ene_val, d[0].ene.data(), sizeof(float) * n);
+    if (stats)
+        for (int k = 0; k < 2; k++) { stats[3 * k] = d[k].pops; stats[3 * k + 1] = d[k].solves; stats[3 * k + 2] = d[k].fills; }
+}
+
+/* prepare_stuff's image part for TV-l2 coupled, src/energy_model.cpp:660-684 */
+extern "C" void orc_preprocess_local(const float *i0, const float *i1, int w, int h, int pd, float *i0n, float *i1n)
+{
+    const size_t n = (size_t)w * h;
+    if (pd != 1) {
+        orc_rgb2gray(i0, w, h, i0n);
+        orc_rgb2gray(i1, w, h, i1n);
+    } else {
+        memcpy(i0n, i0, sizeof(float) * n);
+        memcpy(i1n, i1, sizeof(float) * n);
+    }
+    orc_image_normalization_2(i0n, i1n, i0n, i1n, (int)n);
+    orc_gaussian(i0n, w, h, 0.9f);                                     // PRESMOOTHING_SIGMA
+    orc_gaussian(i1n, w, h, 0.9f);
+}

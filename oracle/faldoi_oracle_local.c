@@ -66,7 +66,15 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
     const float l_t = lambda * theta;
     const size_t n = (size_t)nx * ny;
     float *xi11 = st, *xi12 = st + n, *xi21 = st + 2 * n, *xi22 = st + 3 * n, *div1 = st + 4 * n, *div2 = st + 5 * n;
-    float *w = (float *)calloc(n * 13, sizeof(float));
+    /* scratch planes: kept per thread between calls (the local growing makes millions of calls); every
+     * entry that is read is written first in the same call, except v when no iteration runs */
+    static __thread float *w = NULL;
+    static __thread size_t w_n = 0;
+    if (w_n != n) {
+        free(w);
+        w = (float *)calloc(n * 13, sizeof(float));
+        w_n = n;
+    }
     float *I1w = w, *I1wx = w + n, *I1wy = w + 2 * n, *grad = w + 3 * n, *rho_c = w + 4 * n, *ub1 = w + 5 * n,
           *ub2 = w + 6 * n, *v1 = w + 7 * n, *v2 = w + 8 * n, *u1x = w + 9 * n, *u1y = w + 10 * n, *u2x = w + 11 * n,
           *u2y = w + 12 * n;
@@ -75,6 +83,7 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
         for (int k = ii; k < ei; k++) {
             const int i = l * nx + k;
             xi11[i] = xi12[i] = xi21[i] = xi22[i] = 0.0f;
+            if (max_iter_patch <= 0) v1[i] = v2[i] = 0.0f;
         }
     for (int l = ij; l < ej; l++)                                          /* :325-355, warps = 1 */
         for (int k = ii; k < ei; k++) {
@@ -154,7 +163,6 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
             m++;
         }
     ener = (float)(ener / (m * 1.0));
-    free(w);
     return ener;
 }
 

@@ -19,7 +19,7 @@ def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     import fcntl
     srcs = [os.path.join(_HERE, f) for f in ("faldoi_oracle.c", "faldoi_oracle_nltv.c", "faldoi_oracle_local.c",
-                                             "faldoi_oracle.h")]
+                                             "faldoi_oracle_growing.cpp", "faldoi_oracle.h")]
     fd = os.open(os.path.join(_HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
     try:
         fcntl.flock(fd, fcntl.LOCK_EX)              # several ranks / xdist workers may get here together
@@ -97,6 +97,16 @@ def lib():
         L.orc_interpolate_poisson.argtypes = [_F, _F, _I, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_local_tvl1_estimate.argtypes = [_F] * 7 + [C.c_int] * 7 + [C.POINTER(C.c_int)]
         L.orc_local_tvl1_estimate.restype = C.c_float
+        _FN = C.c_void_p                         # float plane or NULL
+        L.orc_preprocess_local.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, _F, _F]
+        L.orc_local_faldoi.argtypes = [_F, _F, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float, _F, _F,
+                                       np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
+        L.orc_fb_consistency_check.argtypes = [_F, _F, _I, C.c_int, C.c_int, C.c_float]
+        L.orc_fb_consistency_check.restype = C.c_double
+        L.orc_queue_new.restype = C.c_void_p
+        L.orc_queue_free.argtypes = [C.c_void_p]
+        L.orc_queue_push.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.orc_queue_pop.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_float)] * 3
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads(cpu_share())      # libgomp may already be loaded (torch) with its own default
@@ -247,3 +257,25 @@ class LocalTvl1:
         e = lib().orc_local_tvl1_estimate(self.i0, self.i1, self.i1x, self.i1y, u[0], u[1], self.state,
                                           self.w, self.h, ii, ij, ei, ej, max_iter_patch, C.byref(it))
         return float(np.float32(e)), it.value
+
+
+def preprocess_local(i0, i1):
+    """prepare_stuff's image part (TV-l2 coupled): (pd,h,w) or (h,w) frames -> normalised (h,w) pair."""
+    i0, i1 = f32(i0), f32(i1)
+    pd = 1 if i0.ndim == 2 else i0.shape[0]
+    h, w = i0.shape[-2:]
+    a, b = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    lib().orc_preprocess_local(i0, i1, w, h, pd, a, b)
+    return a, b
+
+
+def local_faldoi(i0n, i1n, go, ba, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2.0, sal0=None, sal1=None):
+    """match_growing_variational (-m 0, no partitions).  go/ba: (2,h,w) seed flows, NaN = no seed.
+    Returns (out_flow (2,h,w), ene_val (h,w), stats[6])."""
+    i0n, i1n, go, ba = f32(i0n), f32(i1n), f32(go), f32(ba)
+    h, w = i0n.shape
+    out, ene, st = np.empty((2, h, w), np.float32), np.empty((h, w), np.float32), np.zeros(6, np.int64)
+    keep = [f32(s) if s is not None else None for s in (sal0, sal1)]
+    ptr = [k.ctypes.data if k is not None else None for k in keep]
+    lib().orc_local_faldoi(i0n, i1n, go, ba, ptr[0], ptr[1], w, h, wr, loc_it, max_iter_patch, fb_thresh, out, ene, st)
+    return out, ene, st

@@ -483,3 +483,37 @@ def test_interpolate_poisson_bit_exact(ctx, oracle):
         g.interpolate([pi])
         assert bits_equal(g.get_flow(), u_o), pi
     g.close()
+
+
+def _seed_flows(oracle, a, b, frac, seed):
+    """Sparse integer seeds sampled from the oracle's dense TV-L1 flows (forward and backward)."""
+    h, w = a.shape
+    L = oracle.lib()
+    rng = np.random.default_rng(seed)
+    res = []
+    for src, dst in ((a, b), (b, a)):
+        u = np.zeros((2, h, w), np.float32)
+        xi = np.zeros((4, h, w), np.float32)
+        its, errs = np.zeros(2, np.int32), np.zeros(2, np.float32)
+        L.orc_tvl1_global(src, dst.copy(), u[0], u[1], xi[0], xi[1], xi[2], xi[3], 40, 0.3, 0.125, 0.01, w, h, 2, 60, 1, its, errs)
+        s = np.full_like(u, np.nan)
+        m = rng.random((h, w)) < frac
+        s[:, m] = np.round(u[:, m])
+        res.append(s)
+    return res
+
+
+@pytest.mark.parametrize("crop,frac", [((400, 150, 96, 64), 0.01), ((0, 0, 70, 50), 0.03), ((950, 380, 74, 56), 0.004)])
+def test_match_growing_bit_exact(ctx, oracle, crop, frac):
+    # the whole local step: seeds, 3 x (growing fwd/bwd, pruning, re-seeding), last growing
+    i0, i1 = sintel_pair(crop)
+    a, b = oracle.preprocess_local(i0, i1)
+    ga, gb = ctx.preprocess_local(i0, i1)
+    assert bits_equal(ga, a) and bits_equal(gb, b)
+    go, ba = _seed_flows(oracle, a, b, frac, seed=crop[0])
+    want, want_ene, st = oracle.local_faldoi(a, b, go, ba)
+    got, got_ene, gst = ctx.match_growing(i0, i1, go, ba, budget=3000)
+    assert list(gst.pops) == [st[0], st[3]] and list(gst.solves) == [st[1], st[4]] and list(gst.fills) == [st[2], st[5]]
+    assert bits_equal(got, want), mismatch_report(got, want)
+    assert bits_equal(got_ene, want_ene)
+    assert np.isfinite(got).all()
