@@ -31,7 +31,7 @@ EXPORTS = [
     "faldoi_local_tvl1_get_flow", "faldoi_local_tvl1_estimate", "faldoi_local_tvl1_set_fixed",
     "faldoi_local_tvl1_interpolate",
     "faldoi_local_default_params", "faldoi_preprocess_local", "faldoi_match_growing_variational",
-    "faldoi_match_growing_batch",
+    "faldoi_match_growing_batch", "faldoi_queue_replay",
 ]
 
 
@@ -139,6 +139,8 @@ def lib():
     L.faldoi_preprocess_local.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.c_int, _F, _F]
     L.faldoi_match_growing_variational.argtypes = [vp, _F, _F, _F, _F, vp, vp, C.c_int, C.c_int, C.c_int,
                                                    C.POINTER(LocalParams), _F, _F, C.POINTER(LocalStats)]
+    _I32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    L.faldoi_queue_replay.argtypes = [C.c_int, _I32, _F, _I32, C.POINTER(C.c_int)]
     pp = C.POINTER(C.c_void_p)
     L.faldoi_match_growing_batch.argtypes = [vp, C.c_int, pp, pp, pp, pp, pp, pp, C.c_int, C.c_int, C.c_int,
                                              C.POINTER(LocalParams), pp, pp, C.POINTER(LocalStats)]
@@ -392,6 +394,16 @@ class Tvl1Batch:
         xi = np.empty((4, self.h, self.w), np.float32) if want_xi else None
         _check(lib().faldoi_tvl1_batch_download(self._h, int(pair), u, _ptr(xi)))
         return (u, xi) if want_xi else u
+
+
+def queue_replay(ops, sims):
+    """Replays push (1) / pop (0) operations on the candidate queue (host only).  Returns the popped ids."""
+    ops = np.ascontiguousarray(ops, np.int32)
+    sims = _f32(sims)
+    out = np.empty(len(ops), np.int32)
+    n = C.c_int(0)
+    _check(lib().faldoi_queue_replay(len(ops), ops, sims, out, C.byref(n)))
+    return out[:n.value]
 
 
 def image_to_lab(rgb):

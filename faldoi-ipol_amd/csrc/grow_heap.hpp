@@ -10,7 +10,7 @@
 //   pop : take the last element out as `value`, move the hole from the root to a leaf always
 //         following the child that wins the comparison (the left one on ties), then sift `value`
 //         up from that leaf.
-// The oracle drives the real std::priority_queue; tests compare pop sequences (ties included).
+// tests/ replays random push / pop sequences with many ties against the real std::priority_queue.
 #pragma once
 
 namespace faldoi {

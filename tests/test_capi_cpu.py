@@ -78,3 +78,27 @@ def test_image_to_lab_host_function_matches_the_oracle(oracle):
     a = F.capi.image_to_lab(rgb)
     b = oracle.image_to_lab(rgb)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_candidate_queue_pops_like_std_priority_queue(oracle):
+    # host-only: the product's heap against the container the reference uses, with many equal energies
+    import ctypes as C
+    import numpy as np
+    import faldoi_ipol_amd as F
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    for levels, n in ((3, 200), (8, 4000), (1000, 20000), (2, 65000)):
+        ops = (rng.random(n) < 0.62).astype(np.int32)
+        ops[:10] = 1
+        sims = rng.integers(0, levels, n).astype(np.float32) * 0.25
+        got = F.capi.queue_replay(ops, sims)
+        q = L.orc_queue_new()
+        want = []
+        i, j, u, v, s = C.c_int(), C.c_int(), C.c_float(), C.c_float(), C.c_float()
+        for k in range(n):
+            if ops[k]:
+                L.orc_queue_push(q, k, 0, 0.0, 0.0, float(sims[k]))
+            else:
+                want.append(i.value if L.orc_queue_pop(q, C.byref(i), C.byref(j), C.byref(u), C.byref(v), C.byref(s)) else -1)
+        L.orc_queue_free(q)
+        assert list(got) == want, (levels, n)
