@@ -59,7 +59,8 @@ class LocalParams(C.Structure):
 
 class LocalStats(C.Structure):
     _fields_ = [("pops", C.c_longlong * 2), ("solves", C.c_longlong * 2), ("fills", C.c_longlong * 2),
-                ("fb_kept", C.c_float * 16), ("growing_ms", C.c_float), ("launches", C.c_int)]
+                ("fb_kept", C.c_float * 16), ("growing_ms", C.c_float), ("launches", C.c_int),
+                ("cycles", C.c_longlong * 3)]
 
 
 class FaldoiError(RuntimeError):

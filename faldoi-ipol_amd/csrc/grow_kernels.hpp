@@ -31,6 +31,7 @@ struct GrowCtl {                      // per growing, in HBM
     int done;                         // 1 when the phase has nothing left to process
     int pad;                          // set to 1 if a push did not fit (cannot happen: heap_cap is the worst case)
     long long pops, solves, fills;    // statistics
+    long long cyc_queue, cyc_fill, cyc_solve;   // shader-clock cycles spent by thread 0 in each part
 };
 
 struct GrowDir {                      // per growing: device pointers (array in HBM, one entry per workgroup)
@@ -50,27 +51,40 @@ struct GrowDir {                      // per growing: device pointers (array in 
 
 struct GrowShared {
     float in[2][kElapPyr];            // harmonic fill: data pyramid (NaN = hole), per channel
-    float y[2][kElapPyr];             // harmonic fill: solution pyramid
+    float fin[2][kElapPyr];           // harmonic fill: solution pyramid
+    float ver[2][4][kElapPyr];        // harmonic fill: the level before / after each of the three sweeps
     float a[kPatchThreads], b[kPatchThreads];     // window exchange of ubar / u
     float x[4][kPatchThreads];        // duals of the current iteration
-    float t[kPatchThreads];           // energy terms
-    int err[2];                       // max |du|^2 (float bits), double-buffered
-    int fmax[2];                      // harmonic fill: max update per channel (float bits)
+    alignas(16) float t[kPatchThreads];   // energy terms
+    int err[4];                       // max |du|^2 (float bits) per wavefront, double-buffered
     int cur[4];                       // {have, i, j, pixel}
     int flag;
 };
 
 // ---------------------------------------------------------------------------------------------
-// interpolate_poisson on the window, all 128 threads.  Wave c fills flow channel c.  The sweeps of
-// src/elap_recsep.c:50-69 update in row-major order and each update sees its left and upper
-// neighbours already updated: pixels of one anti-diagonal are independent, so a sweep is run
-// diagonal by diagonal with the lanes of the wave on the pixels of the diagonal -- same values,
-// same order of dependence.  Returns this thread's filled (u1, u2) (threads outside the window: 0).
+// interpolate_poisson on the window.  Wavefront c fills flow channel c on its own (no workgroup
+// barrier inside: LDS operations of one wavefront execute in order).
+//
+// The sweeps of src/elap_recsep.c:50-69 update the holes in row-major order and every update sees
+// its left and upper neighbours already updated, its right and lower ones not yet.  Hence (a) the
+// pixels of one anti-diagonal are independent, and (b) sweep k+1 may work on diagonal d as soon as
+// sweep k has finished diagonal d+1.  Lane group g (16 lanes, lane i = column i) runs sweep g+1 on
+// diagonal step-2g: the three sweeps of a level are in flight together, each writing its own version
+// of the level (ver[g+1]; ver[0] is the initial state), so the values, their order of dependence and
+// the early exit (`maxupdate < 1e-10` after a sweep: the later versions are simply not used) are
+// the reference's.  Returns this thread's filled (u1, u2) (threads outside the window: 0).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float *out, size_t pe, const int *fixed, int nx,
                                                      int ii, int ij, int pw, int ph, float &u1, float &u2)
 {
     const int t = threadIdx.x, c = t >> 6, lane = t & 63;
+    const int g = lane >> 4, i = lane & 15;
     int ws[kElapLevels], hs[kElapLevels], off[kElapLevels];
     ws[0] = pw; hs[0] = ph; off[0] = 0;
 #pragma unroll
@@ -79,21 +93,23 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         hs[s] = (hs[s - 1] + 1) / 2;
         off[s] = off[s - 1] + ws[s - 1] * hs[s - 1];
     }
-    float *in = sm.in[c], *y = sm.y[c];
+    float *in = sm.in[c], *fin = sm.fin[c];
     const float *src = out + (size_t)c * pe;
     for (int q = lane; q < pw * ph; q += 64) {                      // copy_fixed_coordinates + :341-355
         const int xy = (ij + q / pw) * nx + ii + q % pw;
-        in[q] = (fixed[xy] == 1) ? src[xy] : __builtin_nanf("");
+        const int fx = fixed[xy];                                   // both loads in flight, then the selection
+        const float val = src[xy];
+        in[q] = (fx == 1) ? val : __builtin_nanf("");
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int s = 1; s < kElapLevels; ++s) {                         // zoom_out_by_factor_two :160-175
         const int iw = ws[s - 1], ih = hs[s - 1], ow = ws[s];
         if (lane < ow * hs[s]) {
-            const int i = lane % ow, j = lane / ow;
+            const int zi = lane % ow, zj = lane / ow;
             const float *x = in + off[s - 1];
-            const float a4[4] = { px_clamp(x, iw, ih, 2 * i, 2 * j), px_clamp(x, iw, ih, 2 * i + 1, 2 * j),
-                                  px_clamp(x, iw, ih, 2 * i, 2 * j + 1), px_clamp(x, iw, ih, 2 * i + 1, 2 * j + 1) };
+            const float a4[4] = { px_clamp(x, iw, ih, 2 * zi, 2 * zj), px_clamp(x, iw, ih, 2 * zi + 1, 2 * zj),
+                                  px_clamp(x, iw, ih, 2 * zi, 2 * zj + 1), px_clamp(x, iw, ih, 2 * zi + 1, 2 * zj + 1) };
             float m = 0;
             int cx = 0;
 #pragma unroll
@@ -101,53 +117,67 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
                 if (__builtin_isfinite(a4[q])) { m += a4[q]; cx += 1; }
             in[off[s] + lane] = cx ? m / cx : __builtin_nanf("");
         }
-        __syncthreads();
+        wave_sync();
     }
 #pragma unroll
     for (int s = kElapLevels - 1; s >= 0; --s) {
-        const int w = ws[s], h = hs[s];
-        const float *x = in + off[s];
-        float *ys = y + off[s];
+        const int w = ws[s], h = hs[s], o = off[s];
+        const float *x = in + o;
         for (int q = lane; q < w * h; q += 64) {                    // :113-114 with the initialisation of :204-222
             float v = x[q];
-            if (!__builtin_isfinite(v)) {
-                v = 0.0f;                                           // coarsest level starts from zero
-                if (s < kElapLevels - 1)                            // round((i - 0.5) / 2) == i / 2 for i >= 0
-                    v = px_clamp(y + off[s + 1], ws[s + 1], hs[s + 1], (q % w) >> 1, (q / w) >> 1);
-            }
-            ys[q] = v;
+            float coarse = 0.0f;                                    // coarsest level starts from zero
+            if (s < kElapLevels - 1)                                // round((i - 0.5) / 2) == i / 2 for i >= 0
+                coarse = px_clamp(fin + off[s + 1], ws[s + 1], hs[s + 1], (q % w) >> 1, (q / w) >> 1);
+            if (!__builtin_isfinite(v)) v = coarse;
+            sm.ver[c][0][o + q] = v; sm.ver[c][1][o + q] = v; sm.ver[c][2][o + q] = v; sm.ver[c][3][o + q] = v;
         }
-        if (lane == 0) sm.fmax[c] = 0;
-        __syncthreads();
-        bool stop = false;
-        for (int it = 0; it < 3; ++it) {                            // niter = 3, timestep 0.4
-            float mx = 0.0f;
-            for (int d = 0; d < w + h - 1; ++d) {
-                const int i = lane, j = d - lane;
-                if (!stop && i < w && j >= 0 && j < h && __builtin_isnan(x[j * w + i])) {
-                    const int idx = j * w + i;
-                    const float lap = -4 * px_clamp(ys, w, h, i, j) + px_clamp(ys, w, h, i + 1, j) + px_clamp(ys, w, h, i, j + 1)
-                                      + px_clamp(ys, w, h, i - 1, j) + px_clamp(ys, w, h, i, j - 1);
-                    const float nw = ys[idx] + 0.4f * lap;
-                    const float update = __builtin_fabsf(ys[idx] - nw);
-                    if (update > mx) mx = update;
-                    ys[idx] = nw;
-                }
-                __syncthreads();
+        unsigned holes = 0;                                         // bit j: pixel (i, j) of this lane's column is a hole
+        if (g < 3 && i < w) {
+#pragma unroll
+            for (int j = 0; j < kPatchMax; ++j) {                   // clamped row: the loads do not depend on h
+                const float xv = x[(j < h ? j : h - 1) * w + i];
+                holes |= (j < h && __builtin_isnan(xv)) ? (1u << j) : 0u;
             }
-            if (!stop && mx > 0.0f) atomicMax(&sm.fmax[c], __float_as_int(mx));
-            __syncthreads();
-            if ((double)__int_as_float(sm.fmax[c]) < 1e-10) stop = true;         // :66-67
-            __syncthreads();
-            if (lane == 0) sm.fmax[c] = 0;
         }
-        __syncthreads();
+        wave_sync();
+        const float *yo = sm.ver[c][g < 3 ? g : 0] + o;            // state before this group's sweep
+        float *yn = sm.ver[c][g < 3 ? g + 1 : 1] + o;              // state after it
+        float mx = 0.0f;
+        const int steps = w + h - 1 + 4;
+        for (int st = 0; st < steps; ++st) {
+            const int j = st - 2 * g - i;
+            if (j >= 0 && j < h && ((holes >> j) & 1u)) {
+                const int idx = j * w + i;
+                // getpixel_1 clamps to the pixel itself (not yet updated in this sweep); five unconditional loads
+                const float self = yo[idx];
+                const float right = yo[idx + ((i < w - 1) ? 1 : 0)];
+                const float down = yo[idx + ((j < h - 1) ? w : 0)];
+                const float left = *((i > 0) ? yn + idx - 1 : yo + idx);
+                const float up = *((j > 0) ? yn + idx - w : yo + idx);
+                const float lap = -4 * self + right + down + left + up;
+                const float nw = self + 0.4f * lap;
+                const float update = __builtin_fabsf(self - nw);
+                if (update > mx) mx = update;
+                yn[idx] = nw;
+            }
+            wave_sync();
+        }
+#pragma unroll
+        for (int q = 8; q > 0; q >>= 1) {                           // max over each 16-lane group
+            const float other = __shfl_xor(mx, q, 64);
+            mx = other > mx ? other : mx;
+        }
+        const float m1 = __shfl(mx, 0, 64), m2 = __shfl(mx, 16, 64);
+        const int kfin = ((double)m1 < 1e-10) ? 1 : (((double)m2 < 1e-10) ? 2 : 3);     // :66-67
+        for (int q = lane; q < w * h; q += 64) fin[o + q] = sm.ver[c][kfin][o + q];
+        wave_sync();
     }
+    __syncthreads();
     u1 = 0.0f;
     u2 = 0.0f;
     if (t < pw * ph) {
-        u1 = sm.y[0][t];
-        u2 = sm.y[1][t];
+        u1 = sm.fin[0][t];
+        u2 = sm.fin[1][t];
     }
 }
 
@@ -180,8 +210,21 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
     const bool fresh = act && ((k_in && l_in) || (k_in && last_row) || corner || (k_in && first_row && ij == 0) ||
                                (l_in && first_col && ii == 0) || (l_in && last_col && ei == nx));
 
+    // Operand selectors of the divergence (loop invariant).  Every statement of divergence_patch has the form
+    // (P + Q) [+ R] with P in {x1, -left}, Q in {-left, x2, -up}, R in {x2, -up, x2 - up}; a - b is a + (-b) and
+    // -a + b is b + (-a) bit for bit, so selecting the operands replaces ten divergent branches.
+    const bool interior = k_in && l_in;
+    const bool selP_left = last_col && (corner || l_in);                               // -v1[p-1] + ...
+    const bool selQ_left = k_in;                                                       // x1 - left
+    const bool selQ_up = corner && last_row;                                           // ... - v2[p-nx] as 2nd operand
+    const bool selR_none = corner;
+    const bool selR_x2 = k_in && first_row;
+    const int lidx = first_col ? t : t - 1, tidx = first_row ? t : t - pw;             // own slot where the operand is unused
+    const int ridx = last_col ? t : t + 1, didx = last_row ? t : t + pw;
+
     float x11 = 0, x12 = 0, x21 = 0, x22 = 0, rc = 0, wx = 0, wy = 0, gr = 0, v1 = 0, v2 = 0, ub1 = 0, ub2 = 0, d1 = 0, d2 = 0,
           i0 = 0;
+    double rgrad = 0.0;
     if (act) {
         d1 = D1[p];
         d2 = D2[p];
@@ -193,78 +236,58 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         wy = bicubic_eval(I1y, tp, nx);
         gr = grad_sq(wx, wy);
         rc = rho_const(w0, wx, wy, u1, u2, i0);
+        rgrad = recip_f64(gr);
         ub1 = u1;
         ub2 = u2;
     }
+    const double rtheta = 1.0 / (double)theta;
+    sm.a[t] = ub1;
+    sm.b[t] = ub2;
+    __syncthreads();
     int it = 0;
     float err_D = __builtin_inff();
+    // The per-pixel steps are the ones of the global solver (faldoi_device.hpp): same expressions as
+    // src/tvl2_model.cpp:364-427, with the exact-quotient sequences instead of the IEEE divide.
     while (err_D > tol_OF * tol_OF && it < max_iter_patch) {                      // src/tvl2_model.cpp:359
         ++it;
-        if (act) {                                                                // :364-391
-            const float rho = rc + (wx * u1 + wy * u2);
-            float e1, e2;
-            if (rho < -l_t * gr) { e1 = l_t * wx; e2 = l_t * wy; }
-            else if (rho > l_t * gr) { e1 = -l_t * wx; e2 = -l_t * wy; }
-            else if (gr < grad_zero_bound()) { e1 = 0.0f; e2 = 0.0f; }
-            else { const float fi = -rho / gr; e1 = fi * wx; e2 = fi * wy; }
-            v1 = u1 + e1;
-            v2 = u2 + e2;
-        }
-        sm.a[t] = ub1;
-        sm.b[t] = ub2;
-        if (t == 0) sm.err[it & 1] = 0;
-        __syncthreads();
-        if (act) {                                                                // forward_gradient_patch + tvl2coupled_getD
-            const float u1x = !last_col ? sm.a[t + 1] - ub1 : 0.0f, u1y = !last_row ? sm.a[t + pw] - ub1 : 0.0f;
-            const float u2x = !last_col ? sm.b[t + 1] - ub2 : 0.0f, u2y = !last_row ? sm.b[t + pw] - ub2 : 0.0f;
-            const float g11 = x11 * x11, g12 = x12 * x12, g21 = x21 * x21, g22 = x22 * x22;
-            float n = __builtin_sqrtf(g11 + g12 + g21 + g22);
-            n = (1.0f > n) ? 1.0f : n;
-            x11 = (x11 + tau * u1x) / n;
-            x12 = (x12 + tau * u1y) / n;
-            x21 = (x21 + tau * u2x) / n;
-            x22 = (x22 + tau * u2y) / n;
+        if (act) {
+            threshold_step(rc, wx, wy, gr, rgrad, u1, u2, l_t, v1, v2);           // :364-391
+            // forward_gradient_patch (src/utils.cpp:175-220) + tvl2coupled_getD (:82-115)
+            const float ar = sm.a[ridx], ad = sm.a[didx], br = sm.b[ridx], bd = sm.b[didx];
+            const float u1x = !last_col ? ar - ub1 : 0.0f, u1y = !last_row ? ad - ub1 : 0.0f;
+            const float u2x = !last_col ? br - ub2 : 0.0f, u2y = !last_row ? bd - ub2 : 0.0f;
+            dual_step(x11, x12, x21, x22, u1x, u1y, u2x, u2y, tau);
         }
         sm.x[0][t] = x11; sm.x[1][t] = x12; sm.x[2][t] = x21; sm.x[3][t] = x22;
         __syncthreads();
-        float uN = 0.0f;
+        float uNr = 0.0f;
         if (act) {
             if (fresh) {                                                          // divergence_patch, src/utils.cpp:63-113
-                const float l11 = first_col ? 0.0f : sm.x[0][t - 1], l21 = first_col ? 0.0f : sm.x[2][t - 1];
-                const float t12 = first_row ? 0.0f : sm.x[1][t - pw], t22 = first_row ? 0.0f : sm.x[3][t - pw];
-                if (corner) {                                                     // :104-108
-                    if (first_col && first_row) { d1 = x11 + x12; d2 = x21 + x22; }
-                    else if (last_col && first_row) { d1 = -l11 + x12; d2 = -l21 + x22; }
-                    else if (first_col && last_row) { d1 = x11 - t12; d2 = x21 - t22; }
-                    else { d1 = -l11 - t12; d2 = -l21 - t22; }
-                } else if (k_in && l_in) {                                        // :76-86
-                    d1 = (x11 - l11) + (x12 - t12);
-                    d2 = (x21 - l21) + (x22 - t22);
-                } else if (k_in && last_row) {                                    // :91-92
-                    d1 = x11 - l11 - t12;
-                    d2 = x21 - l21 - t22;
-                } else if (k_in) {                                                // :90, image row 0
-                    d1 = x11 - l11 + x12;
-                    d2 = x21 - l21 + x22;
-                } else if (first_col) {                                           // :98-99, image column 0
-                    d1 = x11 + x12 - t12;
-                    d2 = x21 + x22 - t22;
-                } else {                                                          // :100-102, image column nx-1
-                    d1 = -l11 + x12 - t12;
-                    d2 = -l21 + x22 - t22;
-                }
+                const float nl11 = -sm.x[0][lidx], nl21 = -sm.x[2][lidx], nt12 = -sm.x[1][tidx], nt22 = -sm.x[3][tidx];
+                const float s1 = (selP_left ? nl11 : x11) + (selQ_left ? nl11 : (selQ_up ? nt12 : x12));
+                const float s2 = (selP_left ? nl21 : x21) + (selQ_left ? nl21 : (selQ_up ? nt22 : x22));
+                const float r1 = interior ? x12 + nt12 : (selR_x2 ? x12 : nt12);
+                const float r2 = interior ? x22 + nt22 : (selR_x2 ? x22 : nt22);
+                d1 = selR_none ? s1 : s1 + r1;
+                d2 = selR_none ? s2 : s2 + r2;
             }
-            const float u1k = u1, u2k = u2;                                       // tvl2coupled_getP :122-166
-            u1 = u1k - tau * (-d1 + (u1k - v1) / theta);
-            u2 = u2k - tau * (-d2 + (u2k - v2) / theta);
-            uN = (u1 - u1k) * (u1 - u1k) + (u2 - u2k) * (u2 - u2k);
-            ub1 = 2.0f * u1 - u1k;                                                // :420-427
-            ub2 = 2.0f * u2 - u2k;
-            if (uN > 0.0f) atomicMax(&sm.err[it & 1], __float_as_int(uN));        // NaN never wins, as in the reference
+            const float uN = primal_step(u1, u2, ub1, ub2, v1, v2, d1, d2, theta, rtheta, tau);   // :122-166, :420-427
+            uNr = uN > 0.0f ? uN : 0.0f;                                          // NaN never wins, as in the reference
         }
+        // max over the window: butterfly inside each wavefront, then one LDS word per wavefront
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(uNr, o, 64);
+            uNr = other > uNr ? other : uNr;
+        }
+        if ((t & 63) == 0) sm.err[2 * (it & 1) + (t >> 6)] = __float_as_int(uNr);
+        sm.a[t] = ub1;
+        sm.b[t] = ub2;
         __syncthreads();
-        err_D = __int_as_float(sm.err[it & 1]);
+        const float e0 = __int_as_float(sm.err[2 * (it & 1)]), e1 = __int_as_float(sm.err[2 * (it & 1) + 1]);
+        err_D = e1 > e0 ? e1 : e0;
     }
+    __syncthreads();                                     // every read of ubar is done before u overwrites it
 
     // ---- eval_tvl2coupled (src/tvl2_model.cpp:174-243) ----
     sm.a[t] = u1;
@@ -276,8 +299,9 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         base[L_U2 * pe + p] = u2;
         D1[p] = d1;
         D2[p] = d2;
-        const float u1x = !last_col ? sm.a[t + 1] - u1 : 0.0f, u1y = !last_row ? sm.a[t + pw] - u1 : 0.0f;
-        const float u2x = !last_col ? sm.b[t + 1] - u2 : 0.0f, u2y = !last_row ? sm.b[t + pw] - u2 : 0.0f;
+        const float ar = sm.a[ridx], ad = sm.a[didx], br = sm.b[ridx], bd = sm.b[didx];
+        const float u1x = !last_col ? ar - u1 : 0.0f, u1y = !last_row ? ad - u1 : 0.0f;
+        const float u2x = !last_col ? br - u2 : 0.0f, u2y = !last_row ? bd - u2 : 0.0f;
         const BicubicTaps tp = bicubic_taps((float)k + u1, (float)l + u2, nx, ny);
         const float iw = bicubic_eval(I1, tp, nx);
         const float dt = lambda * __builtin_fabsf(iw - i0);
@@ -290,16 +314,120 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
     float ener = 0.0f;
     if (t == 0) {                                        // the reference accumulates in row-major order, in fp32
         const int m = pw * ph;
-        for (int q = 0; q < m; ++q) ener += sm.t[q];
+        float4 v[(kPatchMax * kPatchMax + 3) / 4];       // all LDS reads in flight first, then the ordered sum
+        const float4 *t4 = reinterpret_cast<const float4 *>(sm.t);
+#pragma unroll
+        for (int q = 0; q < (kPatchMax * kPatchMax + 3) / 4; ++q) v[q] = t4[q];
+#pragma unroll
+        for (int q = 0; q < (kPatchMax * kPatchMax + 3) / 4; ++q) {
+            if (4 * q + 0 < m) ener += v[q].x;
+            if (4 * q + 1 < m) ener += v[q].y;
+            if (4 * q + 2 < m) ener += v[q].z;
+            if (4 * q + 3 < m) ener += v[q].w;
+        }
         ener = (float)((double)ener / (m * 1.0));
     }
     return ener;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The candidate queue on the device: the element moves of grow_heap.hpp (the definition, shared with
+// the host), arranged so that one lane has several levels of the tree in flight at once -- a heap
+// walk is a chain of dependent HBM/L2 round trips otherwise.
+//   pop : the children, grandchildren and great-grandchildren of the hole are 2 + 4 + 8 CONSECUTIVE
+//         elements; they are loaded together and three levels are resolved per round trip.
+//   push: the ancestors of the new slot are known from its index alone; eight are loaded at once.
+// ---------------------------------------------------------------------------------------------
+// Elements travel as native 4-vectors {sim, u, v, bits(ij)} with component-wise selection (selecting
+// between structs, or HIP's union-based cand4, goes through memory).
+typedef float cand4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cand4 sel4(bool c, const cand4 a, const cand4 b)
+{
+    cand4 r;
+    r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; r.z = c ? a.z : b.z; r.w = c ? a.w : b.w;
+    return r;
+}
+
+__device__ __forceinline__ void heap_sift_up_dev(cand4 *h, int hole, const cand4 value)
+{
+    while (hole > 0) {
+        const int i0 = ((hole + 1) >> 1) - 1, i1 = ((hole + 1) >> 2) - 1, i2 = ((hole + 1) >> 3) - 1, i3 = ((hole + 1) >> 4) - 1;
+        const int i4 = ((hole + 1) >> 5) - 1, i5 = ((hole + 1) >> 6) - 1, i6 = ((hole + 1) >> 7) - 1, i7 = ((hole + 1) >> 8) - 1;
+        const cand4 a0 = h[i0 < 0 ? 0 : i0], a1 = h[i1 < 0 ? 0 : i1], a2 = h[i2 < 0 ? 0 : i2], a3 = h[i3 < 0 ? 0 : i3];
+        const cand4 a4 = h[i4 < 0 ? 0 : i4], a5 = h[i5 < 0 ? 0 : i5], a6 = h[i6 < 0 ? 0 : i6], a7 = h[i7 < 0 ? 0 : i7];
+        bool placed = false;
+#define FALDOI_SIFT_STEP(IDX, ANC)                                                      \
+        if (!placed) {                                                                  \
+            if ((IDX) < 0 || !((ANC).x > value.x)) placed = true;                       \
+            else { h[hole] = (ANC); hole = (IDX); }                                     \
+        }
+        FALDOI_SIFT_STEP(i0, a0) FALDOI_SIFT_STEP(i1, a1) FALDOI_SIFT_STEP(i2, a2) FALDOI_SIFT_STEP(i3, a3)
+        FALDOI_SIFT_STEP(i4, a4) FALDOI_SIFT_STEP(i5, a5) FALDOI_SIFT_STEP(i6, a6) FALDOI_SIFT_STEP(i7, a7)
+#undef FALDOI_SIFT_STEP
+        if (placed) break;
+    }
+    h[hole] = value;
+}
+
+__device__ __forceinline__ void heap_push_dev(Candidate *heap, int &size, const Candidate &value)
+{
+    heap_sift_up_dev(reinterpret_cast<cand4 *>(heap), size,
+                     cand4{ value.sim, value.u, value.v, __uint_as_float(value.ij) });
+    ++size;
+}
+
+// Removes the top (the caller has read element 0); precondition: size > 0.
+__device__ __forceinline__ void heap_remove_top_dev(Candidate *heap, int &size)
+{
+    cand4 *h = reinterpret_cast<cand4 *>(heap);
+    const int len = --size;
+    if (len == 0) return;
+    const cand4 value = h[len];
+    const int half = (len - 1) / 2;                                 // nodes below `half` have two children
+    const int last = len - 1;
+    int hole = 0;
+    while (hole < half) {
+        const int r1 = 2 * (hole + 1);                              // right child; children = [r1-1, r1],
+        const int e2 = 2 * r1 - 1, e3 = 4 * r1 - 1;                 // grandchildren = [2r1-1, 2r1+2], next = [4r1-1, 4r1+6]
+        const cand4 p0 = h[r1 - 1], p1 = h[r1];
+        const cand4 q0 = h[e2 < last ? e2 : last], q1 = h[e2 + 1 < last ? e2 + 1 : last], q2 = h[e2 + 2 < last ? e2 + 2 : last],
+                     q3 = h[e2 + 3 < last ? e2 + 3 : last];
+        const cand4 s0 = h[e3 < last ? e3 : last], s1 = h[e3 + 1 < last ? e3 + 1 : last], s2 = h[e3 + 2 < last ? e3 + 2 : last],
+                     s3 = h[e3 + 3 < last ? e3 + 3 : last], s4 = h[e3 + 4 < last ? e3 + 4 : last],
+                     s5 = h[e3 + 5 < last ? e3 + 5 : last], s6 = h[e3 + 6 < last ? e3 + 6 : last],
+                     s7 = h[e3 + 7 < last ? e3 + 7 : last];
+        // level 1
+        const bool right1 = !(p1.x > p0.x);                         // comp(right, left) picks the left child
+        h[hole] = sel4(right1, p1, p0);
+        hole = right1 ? r1 : r1 - 1;
+        if (!(hole < half)) break;
+        // level 2: the pair of the chosen child
+        const cand4 a0 = sel4(right1, q2, q0), a1 = sel4(right1, q3, q1);
+        const bool right2 = !(a1.x > a0.x);
+        h[hole] = sel4(right2, a1, a0);
+        const int r2 = 2 * (hole + 1);
+        hole = right2 ? r2 : r2 - 1;
+        if (!(hole < half)) break;
+        // level 3
+        const cand4 b0 = sel4(right1, sel4(right2, s6, s4), sel4(right2, s2, s0));
+        const cand4 b1 = sel4(right1, sel4(right2, s7, s5), sel4(right2, s3, s1));
+        const bool right3 = !(b1.x > b0.x);
+        h[hole] = sel4(right3, b1, b0);
+        const int r3 = 2 * (hole + 1);
+        hole = right3 ? r3 : r3 - 1;
+    }
+    if ((len & 1) == 0 && hole == (len - 2) / 2) {                  // the one node with a single (left) child
+        const int child = 2 * (hole + 1);
+        h[hole] = h[child - 1];
+        hole = child - 1;
+    }
+    heap_sift_up_dev(h, hole, value);
+}
+
 // add_neighbors (src/local_faldoi.cpp:679-727) for the pixel (i, j), all 128 threads.
 __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir &D, size_t pe, int nx, int ny, int i, int j,
                                                   int iteration, int wr, int max_iter_patch, int &heap_size,
-                                                  long long &fills)
+                                                  long long &fills, long long *cyc)
 {
     const int t = threadIdx.x;
     const int ii = (i - wr < 0) ? 0 : i - wr, ij = (j - wr < 0) ? 0 : j - wr;             // get_index_patch
@@ -309,7 +437,26 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
     const int p = (ij + (act ? t / pw : 0)) * nx + ii + (act ? t % pw : 0);
     bool fill = iteration == 0;
     if (!fill) fill = __syncthreads_or(act && D.trust[p] == 0);                   // check_trustable_patch :639-656
+    // thread 0: state of the four neighbours and of the centre, read now so that the latency hides behind the
+    // window computation (only thread 0 ever writes these arrays during a growing)
+    const int nbx[4] = { 0, 0, 1, -1 }, nby[4] = { 1, -1, 0, 0 };                 // insert_candidates :501-505
+    int nfix[4] = { 1, 1, 1, 1 };
+    float nene[4] = { 0, 0, 0, 0 }, nsal[4] = { 1.0f, 1.0f, 1.0f, 1.0f }, cene = 0.0f;
+    if (t == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int px = i + nbx[q], py = j + nby[q];
+            const bool inside = px >= 0 && px < nx && py >= 0 && py < ny;
+            const int g = inside ? py * nx + px : j * nx + i;
+            const int f = D.fixed[g];
+            nfix[q] = inside ? f : 1;
+            nene[q] = D.ene[g];
+            if (D.sal) nsal[q] = D.sal[g];
+        }
+        cene = D.ene[j * nx + i];
+    }
     float u1 = 0.0f, u2 = 0.0f;
+    const long long c0 = clock64();
     if (fill) {
         harmonic_fill_window(sm, D.out, pe, D.fixed, nx, ii, ij, pw, ph, u1, u2);
         if (t == 0) ++fills;
@@ -317,28 +464,30 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
         u1 = D.planes[L_U1 * pe + p];
         u2 = D.planes[L_U2 * pe + p];
     }
+    const long long c1 = clock64();
     const float ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2);
+    const long long c2 = clock64();
     if (t == 0) {                                                                 // insert_candidates :497-537
-        const int nbx[4] = { 0, 0, 1, -1 }, nby[4] = { 1, -1, 0, 0 };
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int px = i + nbx[q], py = j + nby[q];
-            if (px < 0 || px >= nx || py < 0 || py >= ny) continue;
-            const int g = py * nx + px;
-            const float new_ener = ener * (D.sal ? D.sal[g] : 1.0f);
-            if (!D.fixed[g] && new_ener < D.ene[g]) {
-                D.ene[g] = ener;
+            const float new_ener = ener * nsal[q];
+            if (!nfix[q] && new_ener < nene[q]) {                                 // outside the image: nfix = 1
+                D.ene[py * nx + px] = ener;
                 const int wq = (py - ij) * pw + (px - ii);                        // the neighbour lies in the window
-                if (heap_size < D.heap_cap) heap_push(D.heap, heap_size, make_candidate(px, py, sm.a[wq], sm.b[wq], new_ener));
+                if (heap_size < D.heap_cap) heap_push_dev(D.heap, heap_size, make_candidate(px, py, sm.a[wq], sm.b[wq], new_ener));
                 else D.ctl->pad = 1;
             }
         }
         const int g = j * nx + i, wq = (j - ij) * pw + (i - ii);                  // :718-726
-        if (D.ene[g] > ener) {
+        if (cene > ener) {
             D.out[g] = sm.a[wq];
             D.out[pe + g] = sm.b[wq];
             D.ene[g] = ener;
         }
+        cyc[0] += clock64() - c2;
+        cyc[1] += c1 - c0;
+        cyc[2] += c2 - c1;
     }
     __syncthreads();
 }
@@ -352,6 +501,7 @@ __global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__re
     const int t = threadIdx.x;
     int heap_size = 0, seed_pos = 0;
     long long pops = 0, solves = 0, fills = 0;
+    long long cyc[3] = { 0, 0, 0 };
     if (t == 0) {
         heap_size = D.ctl->heap_size;
         seed_pos = D.ctl->seed_pos;
@@ -360,6 +510,7 @@ __global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__re
     for (int step = 0; step < budget; ++step) {
         if (t == 0) {
             int have = 0, g = 0;
+            const long long c0 = clock64();
             if (mode == 0) {
                 if (seed_pos < D.nseeds) {
                     g = D.seeds[seed_pos++];
@@ -370,11 +521,13 @@ __global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__re
                 }
             } else {
                 while (heap_size > 0) {
-                    const Candidate c = heap_pop(D.heap, heap_size);
-                    ++pops;
+                    const Candidate c = D.heap[0];
                     const int ci = (int)(c.ij & 0xffffu), cj = (int)(c.ij >> 16);
                     g = cj * nx + ci;
-                    if (D.fixed[g]) continue;
+                    const int was_fixed = D.fixed[g];                             // in flight during the sift-down
+                    heap_remove_top_dev(D.heap, heap_size);
+                    ++pops;
+                    if (was_fixed) continue;
                     D.fixed[g] = 1;                                               // :926-932
                     D.out[g] = c.u;
                     D.out[pe + g] = c.v;
@@ -383,6 +536,7 @@ __global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__re
                     break;
                 }
             }
+            cyc[0] += clock64() - c0;
             sm.cur[0] = have;
             sm.cur[1] = g % nx;
             sm.cur[2] = g / nx;
@@ -390,7 +544,7 @@ __global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__re
         __syncthreads();
         if (!sm.cur[0]) { done = 1; break; }
         const int i = sm.cur[1], j = sm.cur[2];
-        add_neighbors_dev(sm, D, pe, nx, ny, i, j, iteration, mode == 0 ? 1 : wr, max_iter_patch, heap_size, fills);
+        add_neighbors_dev(sm, D, pe, nx, ny, i, j, iteration, mode == 0 ? 1 : wr, max_iter_patch, heap_size, fills, cyc);
         if (t == 0) {
             ++solves;
             if (mode == 0) {                                                      // :778-780
@@ -409,6 +563,9 @@ __global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__re
         D.ctl->pops += pops;
         D.ctl->solves += solves;
         D.ctl->fills += fills;
+        D.ctl->cyc_queue += cyc[0];
+        D.ctl->cyc_fill += cyc[1];
+        D.ctl->cyc_solve += cyc[2];
     }
 }
 

@@ -246,6 +246,7 @@ typedef struct faldoi_local_stats {
     float fb_kept[16];    /* "FB-Chosen" fraction per local iteration: [2*it] forward, [2*it+1] backward */
     float growing_ms;     /* device time from the first seed to the last pop, incl. the host re-seeding */
     int launches;
+    long long cycles[3];  /* shader-clock cycles summed over growings: queue (pop + push), Poisson fill, minimisation */
 } faldoi_local_stats;
 void faldoi_local_default_params(faldoi_local_params *p);
 /* Host-only replay of the candidate queue (pq_cand, src/energy_structures.h:13-30), for tests of the pop

@@ -1,0 +1,58 @@
+"""Times the local step (match growing) on the GPU and, optionally, the CPU checker on the same seeds.
+usage: python tools/time_growing.py [--crop x0,y0,w,h] [--frac 0.01] [--pairs 1] [--cpu] [--budget N]"""
+import argparse
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
+import faldoi_ipol_amd as F  # noqa: E402
+import util  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--crop", default="")
+ap.add_argument("--frac", type=float, default=0.011)
+ap.add_argument("--pairs", type=int, default=1)
+ap.add_argument("--cpu", action="store_true")
+ap.add_argument("--budget", type=int, default=16384)
+ap.add_argument("--loc_it", type=int, default=3)
+a = ap.parse_args()
+crop = tuple(int(v) for v in a.crop.split(",")) if a.crop else None
+i0, i1 = util.sintel_pair(crop)
+ctx = F.Context()
+i0n, i1n = ctx.preprocess_local(i0, i1)
+h, w = i0n.shape
+rng = np.random.default_rng(1)
+seeds = []
+for src, dst in ((i0n, i1n), (i1n, i0n)):
+    u = ctx.tvl1_global(src, dst, np.zeros((2, h, w), np.float32), warps=5)[0]
+    s = np.full_like(u, np.nan)
+    m = rng.random((h, w)) < a.frac
+    s[:, m] = np.round(u[:, m])
+    seeds.append(s)
+go, ba = seeds
+print("size %dx%d, seeds %d / %d" % (w, h, np.isfinite(go[0]).sum(), np.isfinite(ba[0]).sum()), flush=True)
+t = time.time()
+if a.pairs == 1:
+    out, ene, st = ctx.match_growing(i0, i1, go, ba, budget=a.budget, iterations_of=a.loc_it)
+else:
+    outs, enes, st = ctx.match_growing_batch([i0] * a.pairs, [i1] * a.pairs, [go] * a.pairs, [ba] * a.pairs,
+                                            budget=a.budget, iterations_of=a.loc_it)
+    out = outs[0]
+    assert all(util.bits_equal(o, out) for o in outs)
+dt = time.time() - t
+solves = sum(st.solves)
+print("GPU: %.2f s wall, growing %.2f s, %d windows (%d fills, %d pops) => %.1f k windows/s, %.2f us per window per growing, %d launches"
+      % (dt, st.growing_ms / 1e3, solves, sum(st.fills), sum(st.pops), solves / st.growing_ms, 0.0, st.launches), flush=True)
+cy = list(st.cycles)
+print("cycles per window: queue %.0f, fill %.0f (per fill %.0f), solve %.0f" % (cy[0] / solves, cy[1] / solves, cy[1] / max(1, sum(st.fills)), cy[2] / solves))
+print("FB kept:", [round(v, 4) for v in st.fb_kept[:2 * a.loc_it]], "finite:", float(np.isfinite(out).mean()))
+if a.cpu:
+    from oracle import oracle as O
+    t = time.time()
+    want, wene, ost = O.local_faldoi(i0n, i1n, go, ba, loc_it=a.loc_it)
+    dt = time.time() - t
+    print("CPU checker (2 threads): %.2f s => %.1f k windows/s; bit-identical flow: %s, energy: %s"
+          % (dt, (ost[1] + ost[4]) / dt / 1e3, util.bits_equal(out, want), util.bits_equal(ene if a.pairs == 1 else enes[0], wene)))
