@@ -69,7 +69,7 @@ struct GrowShared {
 // its left and upper neighbours already updated, its right and lower ones not yet.  Hence (a) the
 // pixels of one anti-diagonal are independent, and (b) sweep k+1 may work on diagonal d as soon as
 // sweep k has finished diagonal d+1.  Lane group g (16 lanes, lane i = column i) runs sweep g+1 on
-// diagonal step-2g: the three sweeps of a level are in flight together, each writing its own version
+// diagonal step-3g: the three sweeps of a level are in flight together, each writing its own version
 // of the level (ver[g+1]; ver[0] is the initial state), so the values, their order of dependence and
 // the early exit (`maxupdate < 1e-10` after a sweep: the later versions are simply not used) are
 // the reference's.  Returns this thread's filled (u1, u2) (threads outside the window: 0).
@@ -123,6 +123,25 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
     for (int s = kElapLevels - 1; s >= 0; --s) {
         const int w = ws[s], h = hs[s], o = off[s];
         const float *x = in + o;
+        if (w * h == 1) {
+            // a single pixel: its four neighbours clamp to itself; the three sweeps run in registers
+            if (lane == 0) {
+                float v = x[0];
+                if (!__builtin_isfinite(v)) {
+                    v = (s < kElapLevels - 1) ? fin[off[s + 1]] : 0.0f;
+                    for (int it = 0; it < 3; ++it) {
+                        const float lap = -4 * v + v + v + v + v;
+                        const float nw = v + 0.4f * lap;
+                        const float update = __builtin_fabsf(v - nw);
+                        v = nw;
+                        if ((double)update < 1e-10) break;
+                    }
+                }
+                fin[o] = v;
+            }
+            wave_sync();
+            continue;
+        }
         for (int q = lane; q < w * h; q += 64) {                    // :113-114 with the initialisation of :204-222
             float v = x[q];
             float coarse = 0.0f;                                    // coarsest level starts from zero
@@ -131,35 +150,57 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
             if (!__builtin_isfinite(v)) v = coarse;
             sm.ver[c][0][o + q] = v; sm.ver[c][1][o + q] = v; sm.ver[c][2][o + q] = v; sm.ver[c][3][o + q] = v;
         }
+        const bool lane_on = g < 3 && i < w;
+        const int ic = lane_on ? i : 0;
         unsigned holes = 0;                                         // bit j: pixel (i, j) of this lane's column is a hole
-        if (g < 3 && i < w) {
+        if (lane_on) {
 #pragma unroll
             for (int j = 0; j < kPatchMax; ++j) {                   // clamped row: the loads do not depend on h
                 const float xv = x[(j < h ? j : h - 1) * w + i];
                 holes |= (j < h && __builtin_isnan(xv)) ? (1u << j) : 0u;
             }
         }
+        // the column to the left (lane i-1 of the same 16-lane group); row_shr:1, zero at the row start
+        const unsigned holes_left = (unsigned)__builtin_amdgcn_update_dpp(0, (int)holes, 0x111, 0xf, 0xf, true);
         wave_sync();
-        const float *yo = sm.ver[c][g < 3 ? g : 0] + o;            // state before this group's sweep
-        float *yn = sm.ver[c][g < 3 ? g + 1 : 1] + o;              // state after it
-        float mx = 0.0f;
-        const int steps = w + h - 1 + 4;
+        const float *y0 = sm.ver[c][0] + o;                         // initial state: the value of every non-hole
+        const float *yo = sm.ver[c][g < 3 ? g : 0] + o;             // state before this group's sweep
+        float *yn = sm.ver[c][g < 3 ? g + 1 : 1] + o;               // state after it
+        // Group g works on diagonal st - 3g.  What a pixel needs from the previous sweep (itself, right, lower
+        // neighbour) was stored at least two steps ago and is loaded one step ahead; what it needs from its own
+        // sweep was computed in the previous step: the upper neighbour by this lane (register), the left one by
+        // lane i-1 (DPP).  Neighbours that are not holes keep their initial value in every version.
+        int j = -3 * g - i;
+        float self, right, down, sleft, self_prev = 0.0f, nw = 0.0f, mx = 0.0f;
+        {
+            const int jc = j < 0 ? 0 : (j > h - 1 ? h - 1 : j);
+            const int idx = jc * w + ic;
+            self = yo[idx];
+            right = yo[idx + ((ic < w - 1) ? 1 : 0)];
+            down = yo[idx + ((jc < h - 1) ? w : 0)];
+            sleft = y0[idx - ((ic > 0) ? 1 : 0)];
+        }
+        const int steps = w + h - 1 + 6;
         for (int st = 0; st < steps; ++st) {
-            const int j = st - 2 * g - i;
-            if (j >= 0 && j < h && ((holes >> j) & 1u)) {
-                const int idx = j * w + i;
-                // getpixel_1 clamps to the pixel itself (not yet updated in this sweep); five unconditional loads
-                const float self = yo[idx];
-                const float right = yo[idx + ((i < w - 1) ? 1 : 0)];
-                const float down = yo[idx + ((j < h - 1) ? w : 0)];
-                const float left = *((i > 0) ? yn + idx - 1 : yo + idx);
-                const float up = *((j > 0) ? yn + idx - w : yo + idx);
+            const float left_nw = __builtin_amdgcn_update_dpp(0.0f, nw, 0x111, 0xf, 0xf, true);
+            const int jn = j + 1, jc = jn < 0 ? 0 : (jn > h - 1 ? h - 1 : jn);
+            const int idxn = jc * w + ic;
+            const float self_n = yo[idxn], right_n = yo[idxn + ((ic < w - 1) ? 1 : 0)], down_n = yo[idxn + ((jc < h - 1) ? w : 0)];
+            const float sleft_n = y0[idxn - ((ic > 0) ? 1 : 0)];
+            if (lane_on && j >= 0 && j < h && ((holes >> j) & 1u)) {
+                // getpixel_1 clamps to the pixel itself, not yet updated in this sweep
+                const float left = (i > 0) ? (((holes_left >> j) & 1u) ? left_nw : sleft) : self;
+                const float up = (j > 0) ? (((holes >> (j - 1)) & 1u) ? nw : self_prev) : self;
                 const float lap = -4 * self + right + down + left + up;
-                const float nw = self + 0.4f * lap;
-                const float update = __builtin_fabsf(self - nw);
+                const float res = self + 0.4f * lap;
+                const float update = __builtin_fabsf(self - res);
                 if (update > mx) mx = update;
-                yn[idx] = nw;
+                yn[j * w + i] = res;
+                nw = res;
             }
+            self_prev = self;
+            self = self_n; right = right_n; down = down_n; sleft = sleft_n;
+            j = jn;
             wave_sync();
         }
 #pragma unroll

@@ -5,6 +5,8 @@ implementation is held to the stricter bar the design allows -- BIT-IDENTICAL fl
 per-warp iteration counts and errors -- and the EPE gate is asserted as well so a future
 relaxation (e.g. fused multiply-add) has a written tolerance to answer to.
 """
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -517,3 +519,49 @@ def test_match_growing_bit_exact(ctx, oracle, crop, frac):
     assert bits_equal(got, want), mismatch_report(got, want)
     assert bits_equal(got_ene, want_ene)
     assert np.isfinite(got).all()
+
+
+def test_three_cli_pipeline_matches_cpu_path(ctx, oracle, tmp_path):
+    # sparse_flow -> local_faldoi -> global_faldoi (the stage order of scripts_python/faldoi_sift.py:274-318) on a crop,
+    # from match lists; every stage byte-identical to the CPU checker's
+    from PIL import Image
+    bins = F.build.build_host()
+    crop = (380, 140, 112, 80)
+    i0, i1 = sintel_pair(crop)
+    h, w = i0.shape[1:]
+    for k, im in enumerate((i0, i1)):
+        Image.fromarray(im.transpose(1, 2, 0).astype(np.uint8), "RGB").save(tmp_path / ("f%d.png" % k))
+    (tmp_path / "ims.txt").write_text("%s\n%s\n" % (tmp_path / "f0.png", tmp_path / "f1.png"))
+    a, b = oracle.preprocess_local(i0, i1)
+    go, ba = _seed_flows(oracle, a, b, 0.012, seed=11)
+    for name, s in (("m0.txt", go), ("m1.txt", ba)):                 # match lists "x0 y0 x1 y1"
+        ys, xs = np.nonzero(np.isfinite(s[0]))
+        with open(tmp_path / name, "w") as f:
+            for y, x in zip(ys, xs):
+                f.write("%d %d %d %d\n" % (x, y, x + int(s[0, y, x]), y + int(s[1, y, x])))
+    run = lambda *cmd: subprocess.run([str(c) for c in cmd], capture_output=True, text=True)
+    for m, o in (("m0.txt", "s0.flo"), ("m1.txt", "s1.flo")):
+        r = run(bins["sparse_flow"], tmp_path / m, w, h, tmp_path / o)
+        assert r.returncode == 0, r.stderr
+    go, ba = F.flo.read_flo(str(tmp_path / "s0.flo")), F.flo.read_flo(str(tmp_path / "s1.flo"))
+    assert np.isfinite(go[0]).sum() > 50 and np.isfinite(ba[0]).sum() > 50
+    r = run(bins["local_faldoi"], tmp_path / "ims.txt", tmp_path / "s0.flo", tmp_path / "s1.flo", tmp_path / "local.flo",
+            tmp_path / "sim.tiff", "-m", 0, "-wr", 5, "-loc_it", 3, "-max_pch_it", 4, "-split_img", 0, "-h_parts", 3,
+            "-v_parts", 2, "-fb_thresh", 2, "-partial_res", 0, "-verbose", 0)
+    assert r.returncode == 0, r.stderr + r.stdout
+    want_local, want_ene, _ = oracle.local_faldoi(a, b, go, ba)
+    got_local = F.flo.read_flo(str(tmp_path / "local.flo"))
+    assert bits_equal(got_local, want_local), mismatch_report(got_local, want_local)
+    sim = open(tmp_path / "sim.tiff").read().split()
+    assert sim[:4] == ["P2", str(w), str(h), "65535"]
+    assert np.array_equal(np.array([float.fromhex(v) for v in sim[4:]], np.float32), want_ene.ravel())
+    r = run(bins["global_faldoi"], tmp_path / "ims.txt", tmp_path / "local.flo", tmp_path / "final.flo", "-m", 0, "-w", 5)
+    assert r.returncode == 0, r.stderr
+    # CPU path of the global step from the same local flow (2-line list: I-1 := I1 in the normalisation)
+    g0, g1 = oracle.preprocess_global(i0, i1, None)
+    u = want_local.copy()
+    xi = np.zeros((4, h, w), np.float32)
+    its, errs = np.zeros(5, np.int32), np.zeros(5, np.float32)
+    oracle.lib().orc_tvl1_global(g0, g1.copy(), u[0], u[1], xi[0], xi[1], xi[2], xi[3], 40, 0.3, 0.125, 0.01, w, h, 5, 400, 1, its, errs)
+    got = F.flo.read_flo(str(tmp_path / "final.flo"))
+    assert bits_equal(got, u), mismatch_report(got, u)

@@ -102,3 +102,37 @@ def test_global_faldoi_cli_argument_handling(bins, tmp_path):
         r = subprocess.run([exe, str(ims), str(z), str(tmp_path / "o.flo")], capture_output=True, text=True)
         assert r.returncode == 3 and "no usable GPU" in r.stderr
         assert not (tmp_path / "o.flo").exists()
+
+
+def test_local_faldoi_cli_argument_handling(bins, tmp_path):
+    exe = bins["local_faldoi"]
+    r = subprocess.run([exe, "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+    f2, f3 = (os.path.join(GOLDEN, "sintel_clean_easy_frame_000%d.png" % k) for k in (2, 3))
+    ims = tmp_path / "ims.txt"
+    ims.write_text(f2 + "\n" + f3 + "\n")
+    seeds = np.full((2, 436, 1024), np.nan, np.float32)
+    seeds[:, 100, 200] = 1.0
+    s0 = tmp_path / "s0.flo"
+    F.flo.write_flo(str(s0), seeds)
+    base = [exe, str(ims), str(s0), str(s0), str(tmp_path / "o.flo"), str(tmp_path / "sim.tiff")]
+    r = subprocess.run(base + ["-m", "2"], capture_output=True, text=True)          # functional not built
+    assert r.returncode == 2 and "not available" in r.stderr
+    r = subprocess.run(base + ["-split_img", "1"], capture_output=True, text=True)  # partitioning not built
+    assert r.returncode == 2 and "partitioning" in r.stderr
+    r = subprocess.run(base + ["occ.png"], capture_output=True, text=True)          # occlusion outputs not built
+    assert r.returncode == 2
+    ims3 = tmp_path / "ims3.txt"
+    ims3.write_text(f2 + "\n" + f3 + "\n" + f2 + "\n")                            # src/local_faldoi.cpp:1852
+    r = subprocess.run([exe, str(ims3)] + base[2:], capture_output=True, text=True)
+    assert r.returncode == 1 and "3 images given as input" in r.stderr
+    small = tmp_path / "small.flo"
+    F.flo.write_flo(str(small), np.zeros((2, 4, 4), np.float32))
+    r = subprocess.run([exe, str(ims), str(small), str(small), base[4], base[5]], capture_output=True, text=True)
+    assert r.returncode == 1 and "flow field size mismatch" in r.stderr
+    import ctypes
+    n = ctypes.c_int(0)
+    if F.capi.lib().faldoi_device_count(ctypes.byref(n)) != 0:       # CI container: no GPU, no fallback
+        r = subprocess.run(base, capture_output=True, text=True)
+        assert r.returncode == 3 and "no usable GPU" in r.stderr
+        assert not (tmp_path / "o.flo").exists()
