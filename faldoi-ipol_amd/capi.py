@@ -32,6 +32,7 @@ EXPORTS = [
     "faldoi_local_tvl1_interpolate",
     "faldoi_local_default_params", "faldoi_preprocess_local", "faldoi_match_growing_variational",
     "faldoi_match_growing_batch", "faldoi_queue_replay",
+    "faldoi_fb_consistency_check",
 ]
 
 
@@ -142,6 +143,7 @@ def lib():
                                                    C.POINTER(LocalParams), _F, _F, C.POINTER(LocalStats)]
     _I32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
     L.faldoi_queue_replay.argtypes = [C.c_int, _I32, _F, _I32, C.POINTER(C.c_int)]
+    L.faldoi_fb_consistency_check.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.c_float, _I32, C.POINTER(C.c_int)]
     pp = C.POINTER(C.c_void_p)
     L.faldoi_match_growing_batch.argtypes = [vp, C.c_int, pp, pp, pp, pp, pp, pp, C.c_int, C.c_int, C.c_int,
                                              C.POINTER(LocalParams), pp, pp, C.POINTER(LocalStats)]
@@ -241,6 +243,14 @@ class Context:
         o0, o1 = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
         _check(lib().faldoi_preprocess_local(self._h, i0, i1, w, h, pd, o0, o1))
         return o0, o1
+
+    def fb_consistency_check(self, in0, in1, epsilon=2.0):
+        """Mirror of fb_consistency_check: (2,h,w) forward / backward flows -> trust (h,w) int32."""
+        in0, in1 = _f32(in0), _f32(in1)
+        h, w = in0.shape[1:]
+        trust = np.empty((h, w), np.int32)
+        _check(lib().faldoi_fb_consistency_check(self._h, in0, in1, w, h, epsilon, trust, None))
+        return trust
 
     @staticmethod
     def _local_params(params):

@@ -256,6 +256,11 @@ int faldoi_queue_replay(int nops, const int *ops, const float *sims, int *popped
  * over the two frames (src/utils.cpp:703-734), Gaussian 0.9. */
 int faldoi_preprocess_local(faldoi_ctx *ctx, const float *i0, const float *i1, int nx, int ny, int pd, float *i0n,
                             float *i1n);
+/* fb_consistency_check(in0, in1, trust_in0, w, h, epsilon), src/local_faldoi.cpp:167-190: in0 / in1 = forward /
+ * backward flow (2 planes each); trust[p] = 0 where |in0(x) + in1(x + in0(x))| > epsilon (bicubic, 0 outside),
+ * 1 elsewhere; *kept (may be NULL) = number of ones ("FB-Chosen"). */
+int faldoi_fb_consistency_check(faldoi_ctx *ctx, const float *in0, const float *in1, int nx, int ny, float epsilon,
+                                int *trust, int *kept);
 int faldoi_match_growing_variational(faldoi_ctx *ctx, const float *go, const float *ba, const float *i0, const float *i1,
                                      const float *sal_go, const float *sal_ba, int nx, int ny, int pd,
                                      const faldoi_local_params *params, float *ene_val, float *out_flow,

@@ -565,3 +565,67 @@ def test_three_cli_pipeline_matches_cpu_path(ctx, oracle, tmp_path):
     oracle.lib().orc_tvl1_global(g0, g1.copy(), u[0], u[1], xi[0], xi[1], xi[2], xi[3], 40, 0.3, 0.125, 0.01, w, h, 5, 400, 1, its, errs)
     got = F.flo.read_flo(str(tmp_path / "final.flo"))
     assert bits_equal(got, u), mismatch_report(got, u)
+
+
+def test_match_growing_options_saliency_and_empty_direction(ctx, oracle):
+    # non-default radius / iteration counts, saliency maps, and a backward direction without any seed
+    i0, i1 = sintel_pair((600, 200, 64, 48))
+    a, b = oracle.preprocess_local(i0, i1)
+    go, ba = _seed_flows(oracle, a, b, 0.02, seed=4)
+    rng = np.random.default_rng(9)
+    sal0 = rng.uniform(0.5, 1.5, a.shape).astype(np.float32)
+    sal1 = rng.uniform(0.5, 1.5, a.shape).astype(np.float32)
+    want, wene, st = oracle.local_faldoi(a, b, go, ba, wr=3, loc_it=2, max_iter_patch=2, fb_thresh=1.0, sal0=sal0, sal1=sal1)
+    got, gene, gst = ctx.match_growing(a, b, go, ba, sal0, sal1, preprocessed=1, wr=3, loc_it=2, max_iter_patch=2, fb_thresh=1.0,
+                                       budget=777)
+    assert bits_equal(got, want), mismatch_report(got, want)
+    assert bits_equal(gene, wene) and list(gst.solves) == [st[1], st[4]]
+    none = np.full_like(ba, np.nan)
+    want, wene, st = oracle.local_faldoi(a, b, go, none, loc_it=1)
+    got, gene, gst = ctx.match_growing(a, b, go, none, preprocessed=1, loc_it=1)
+    assert st[4] == 0 and list(gst.solves) == [st[1], 0]
+    assert bits_equal(got, want), mismatch_report(got, want)
+    want, wene, st = oracle.local_faldoi(a, b, go, ba, loc_it=0)             # a single forward growing
+    got, gene, gst = ctx.match_growing(a, b, go, ba, preprocessed=1, loc_it=0)
+    assert bits_equal(got, want) and bits_equal(gene, wene)
+
+
+def test_match_growing_batch_of_different_pairs(ctx, oracle):
+    # several pairs in one launch sequence (one workgroup per growing): each equals its own sequential CPU run
+    crops = [(100, 50, 56, 40), (500, 300, 56, 40), (900, 10, 56, 40)]
+    ins = []
+    for k, crop in enumerate(crops):
+        i0, i1 = sintel_pair(crop)
+        a, b = oracle.preprocess_local(i0, i1)
+        go, ba = _seed_flows(oracle, a, b, 0.02, seed=20 + k)
+        ins.append((i0, i1, a, b, go, ba))
+    outs, enes, st = ctx.match_growing_batch([x[0] for x in ins], [x[1] for x in ins], [x[4] for x in ins],
+                                             [x[5] for x in ins], budget=2000)
+    total = 0
+    for (i0, i1, a, b, go, ba), out, ene in zip(ins, outs, enes):
+        want, wene, ost = oracle.local_faldoi(a, b, go, ba)
+        total += ost[1] + ost[4]
+        assert bits_equal(out, want), mismatch_report(out, want)
+        assert bits_equal(ene, wene)
+    assert sum(st.solves) == total
+
+
+def test_fb_consistency_check_at_the_threshold(ctx, oracle):
+    # |u + v(x+u)| within a few ulps of epsilon: the C library's hypotf decides on the CPU, sqrt(x*x + y*y) in
+    # double on the device; plus a generic case with sub-pixel warps, borders and NaN holes
+    h, w = 40, 64
+    rng = np.random.default_rng(2)
+    ang = rng.uniform(0, 2 * np.pi, (h, w))
+    r = np.float32(2.0) * (1 + rng.integers(-3, 4, (h, w)) * np.float32(2.0 ** -23))
+    go = np.zeros((2, h, w), np.float32)                       # zero forward flow: the warp is the identity
+    ba = np.stack([(r * np.cos(ang)), (r * np.sin(ang))]).astype(np.float32)
+    trust = np.zeros((h, w), np.int32)
+    oracle.lib().orc_fb_consistency_check(go, ba, trust, w, h, 2.0)
+    assert 0.2 < trust[3:-3, 3:-3].mean() < 0.8
+    assert np.array_equal(ctx.fb_consistency_check(go, ba, 2.0), trust)
+    go = (rng.standard_normal((2, h, w)) * 2).astype(np.float32)
+    ba = (-go + rng.standard_normal((2, h, w)) * 1.5).astype(np.float32)
+    ba[:, 5:9, 7:12] = np.nan
+    go[:, 20:22, 30:33] = np.nan
+    oracle.lib().orc_fb_consistency_check(go, ba, trust, w, h, 2.0)
+    assert np.array_equal(ctx.fb_consistency_check(go, ba, 2.0), trust)
