@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--growing-pairs", type=int, default=256)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -155,6 +156,42 @@ def main():
                 "device_ms": round(nl_ms, 2), "Mpx_iter_per_s": round(W * H * 400 / nl_ms / 1e3, 1),
                 "algorithmic_GBps": round(720.0 * W * H * 400 / (nl_ms * 1e-3) / 1e9, 1),
                 "note": "two streaming launches per iteration, ~720 B/px/iteration (SURVEY 8d, approximate)"}}
+        if world == 1 and data_kind != "synthetic" and not args.no_secondary:
+            # SURVEY 8f-1 (not the headline): the local step (match growing).  One growing is a sequential
+            # priority-queue process (one workgroup each); the device runs the growings of many pairs at once.
+            gp, gw, gh = args.growing_pairs, 256, 192
+            full0, full1 = load_rgb_planar(f2), load_rgb_planar(f3)
+            rng = np.random.default_rng(7)
+            g_i0, g_i1, g_go, g_ba = [], [], [], []
+            for k in range(gp):
+                x0, y0 = (k * 37) % (W - gw), (k * 53) % (H - gh)
+                c0 = np.ascontiguousarray(full0[:, y0:y0 + gh, x0:x0 + gw])
+                c1 = np.ascontiguousarray(full1[:, y0:y0 + gh, x0:x0 + gw])
+                a, b = ctx.preprocess_local(c0, c1)
+                sd = []
+                for src, dst in ((a, b), (b, a)):           # seeds: ~1 % of a dense TV-L1 flow, rounded (matcher-like)
+                    dense = ctx.tvl1_global(src, dst, np.zeros((2, gh, gw), np.float32), warps=3)[0]
+                    sp = np.full_like(dense, np.nan)
+                    m = rng.random((gh, gw)) < 0.011
+                    sp[:, m] = np.round(dense[:, m])
+                    sd.append(sp)
+                g_i0.append(c0); g_i1.append(c1); g_go.append(sd[0]); g_ba.append(sd[1])
+            g_out, _, gst = ctx.match_growing_batch(g_i0, g_i1, g_go, g_ba)
+            windows = int(sum(gst.solves))
+            grow = {"pairs": gp, "size": "%dx%d" % (gw, gh), "windows": windows, "device_ms": round(gst.growing_ms, 1),
+                    "windows_per_s": round(windows / (gst.growing_ms * 1e-3), 0),
+                    "note": "seeds -> 3 x (growing fwd+bwd, FB pruning, re-seeding) -> last growing; every candidate on the "
+                            "device, in the reference's order"}
+            if not args.no_cpu_baseline:
+                from oracle import oracle as O
+                a, b = O.preprocess_local(g_i0[0], g_i1[0])
+                t1 = time.perf_counter()
+                want, _, ost = O.local_faldoi(a, b, g_go[0], g_ba[0])
+                cpu_s = time.perf_counter() - t1
+                grow["cpu_windows_per_s"] = round((ost[1] + ost[4]) / cpu_s, 0)
+                grow["cpu_sample"] = "pair 0 once, forward and backward on 2 threads (%.1f s)" % cpu_s
+                grow["bit_identical_pair0"] = bool(np.array_equal(g_out[0].view(np.uint32), want.view(np.uint32)))
+            out.setdefault("secondary", {})["local_match_growing"] = grow
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O            # checker + timed CPU baseline only
             i0n, i1n, u0 = pairs[0]

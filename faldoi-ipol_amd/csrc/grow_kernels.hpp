@@ -382,6 +382,7 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
 // Elements travel as native 4-vectors {sim, u, v, bits(ij)} with component-wise selection (selecting
 // between structs, or HIP's union-based cand4, goes through memory).
 typedef float cand4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) cand4 *heap_ptr;      // the queue lives in global memory: plain global loads, not flat ones
 __device__ __forceinline__ cand4 sel4(bool c, const cand4 a, const cand4 b)
 {
     cand4 r;
@@ -389,7 +390,7 @@ __device__ __forceinline__ cand4 sel4(bool c, const cand4 a, const cand4 b)
     return r;
 }
 
-__device__ __forceinline__ void heap_sift_up_dev(cand4 *h, int hole, const cand4 value)
+__device__ __forceinline__ void heap_sift_up_dev(heap_ptr h, int hole, const cand4 value)
 {
     while (hole > 0) {
         const int i0 = ((hole + 1) >> 1) - 1, i1 = ((hole + 1) >> 2) - 1, i2 = ((hole + 1) >> 3) - 1, i3 = ((hole + 1) >> 4) - 1;
@@ -412,7 +413,7 @@ __device__ __forceinline__ void heap_sift_up_dev(cand4 *h, int hole, const cand4
 
 __device__ __forceinline__ void heap_push_dev(Candidate *heap, int &size, const Candidate &value)
 {
-    heap_sift_up_dev(reinterpret_cast<cand4 *>(heap), size,
+    heap_sift_up_dev((heap_ptr)(heap), size,
                      cand4{ value.sim, value.u, value.v, __uint_as_float(value.ij) });
     ++size;
 }
@@ -420,7 +421,7 @@ __device__ __forceinline__ void heap_push_dev(Candidate *heap, int &size, const 
 // Removes the top (the caller has read element 0); precondition: size > 0.
 __device__ __forceinline__ void heap_remove_top_dev(Candidate *heap, int &size)
 {
-    cand4 *h = reinterpret_cast<cand4 *>(heap);
+    heap_ptr h = (heap_ptr)(heap);
     const int len = --size;
     if (len == 0) return;
     const cand4 value = h[len];

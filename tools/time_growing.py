@@ -44,8 +44,8 @@ else:
     assert all(util.bits_equal(o, out) for o in outs)
 dt = time.time() - t
 solves = sum(st.solves)
-print("GPU: %.2f s wall, growing %.2f s, %d windows (%d fills, %d pops) => %.1f k windows/s, %.2f us per window per growing, %d launches"
-      % (dt, st.growing_ms / 1e3, solves, sum(st.fills), sum(st.pops), solves / st.growing_ms, 0.0, st.launches), flush=True)
+print("GPU: %.2f s wall, growing %.2f s, %d windows (%d fills, %d pops) => %.1f k windows/s, %d launches"
+      % (dt, st.growing_ms / 1e3, solves, sum(st.fills), sum(st.pops), solves / st.growing_ms, st.launches), flush=True)
 cy = list(st.cycles)
 print("cycles per window: queue %.0f, fill %.0f (per fill %.0f), solve %.0f" % (cy[0] / solves, cy[1] / solves, cy[1] / max(1, sum(st.fills)), cy[2] / solves))
 print("FB kept:", [round(v, 4) for v in st.fb_kept[:2 * a.loc_it]], "finite:", float(np.isfinite(out).mean()))
