@@ -6,8 +6,10 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, "tests")
-sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import faldoi_ipol_amd as F  # noqa: E402
 import util  # noqa: E402
 
