@@ -22,6 +22,7 @@ HOST_COMMON = [os.path.join(HOST, "image_io.cpp")]
 HOST_PROGRAMS = {          # name -> (sources, needs libfaldoi_hip)
     "global_faldoi": ([os.path.join(HOST, "global_faldoi.cpp")], True),
     "local_faldoi": ([os.path.join(HOST, "local_faldoi.cpp")], True),
+    "faldoi_flow": ([os.path.join(HOST, "faldoi_flow.cpp")], True),
     "sparse_flow": ([os.path.join(HOST, "sparse_flow.cpp")], False),
     "faldoi_imginfo": ([os.path.join(HOST, "imginfo.cpp")], False),
 }

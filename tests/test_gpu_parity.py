@@ -565,6 +565,17 @@ def test_three_cli_pipeline_matches_cpu_path(ctx, oracle, tmp_path):
     oracle.lib().orc_tvl1_global(g0, g1.copy(), u[0], u[1], xi[0], xi[1], xi[2], xi[3], 40, 0.3, 0.125, 0.01, w, h, 5, 400, 1, its, errs)
     got = F.flo.read_flo(str(tmp_path / "final.flo"))
     assert bits_equal(got, u), mismatch_report(got, u)
+    # the one-process driver (no intermediate files) gives the same bytes; "sift" layout = match_cli columns 2,1,6,5
+    for name in ("m0.txt", "m1.txt"):
+        with open(tmp_path / name) as f, open(tmp_path / ("raw_" + name), "w") as g:
+            for line in f:
+                x0, y0, x1, y1 = line.split()
+                g.write("%s %s 1.5 0.3 %s %s 1.6 0.2 77\n" % (y0, x0, y1, x1))
+    r = run(bins["faldoi_flow"], tmp_path / "ims.txt", tmp_path / "raw_m0.txt", tmp_path / "raw_m1.txt", tmp_path / "flow.flo",
+            "-local_out", tmp_path / "local2.flo")
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "flow.flo").read_bytes() == (tmp_path / "final.flo").read_bytes()
+    assert (tmp_path / "local2.flo").read_bytes() == (tmp_path / "local.flo").read_bytes()
 
 
 def test_match_growing_options_saliency_and_empty_direction(ctx, oracle):

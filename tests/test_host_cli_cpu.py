@@ -136,3 +136,23 @@ def test_local_faldoi_cli_argument_handling(bins, tmp_path):
         r = subprocess.run(base, capture_output=True, text=True)
         assert r.returncode == 3 and "no usable GPU" in r.stderr
         assert not (tmp_path / "o.flo").exists()
+
+
+def test_faldoi_flow_cli_argument_handling(bins, tmp_path):
+    exe = bins["faldoi_flow"]
+    r = subprocess.run([exe, "ims.txt"], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+    f2, f3 = (os.path.join(GOLDEN, "sintel_clean_easy_frame_000%d.png" % k) for k in (2, 3))
+    ims = tmp_path / "ims.txt"
+    ims.write_text(f2 + "\n" + f3 + "\n")
+    m = tmp_path / "m.txt"
+    m.write_text("10 20 1 1 12 21 1 1 5\n")
+    r = subprocess.run([exe, str(ims), str(m), str(m), str(tmp_path / "o.flo"), "-matcher", "surf"], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+    r = subprocess.run([exe, str(ims), str(tmp_path / "missing.txt"), str(m), str(tmp_path / "o.flo")], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+    import ctypes
+    n = ctypes.c_int(0)
+    if F.capi.lib().faldoi_device_count(ctypes.byref(n)) != 0:       # CI container: no GPU, no fallback
+        r = subprocess.run([exe, str(ims), str(m), str(m), str(tmp_path / "o.flo")], capture_output=True, text=True)
+        assert r.returncode == 3 and "no usable GPU" in r.stderr
