@@ -32,7 +32,7 @@ EXPORTS = [
     "faldoi_local_tvl1_interpolate",
     "faldoi_local_default_params", "faldoi_preprocess_local", "faldoi_match_growing_variational",
     "faldoi_match_growing_batch", "faldoi_queue_replay",
-    "faldoi_fb_consistency_check",
+    "faldoi_fb_consistency_check", "faldoi_tvcsad_default_params", "faldoi_tvcsad_global",
 ]
 
 
@@ -144,6 +144,9 @@ def lib():
     _I32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
     L.faldoi_queue_replay.argtypes = [C.c_int, _I32, _F, _I32, C.POINTER(C.c_int)]
     L.faldoi_fb_consistency_check.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.c_float, _I32, C.POINTER(C.c_int)]
+    L.faldoi_tvcsad_default_params.argtypes = [C.POINTER(Tvl1Params)]
+    L.faldoi_tvcsad_default_params.restype = None
+    L.faldoi_tvcsad_global.argtypes = [vp, _F, _F, _F, vp, C.c_int, C.c_int, C.POINTER(Tvl1Params), C.POINTER(Tvl1Stats)]
     pp = C.POINTER(C.c_void_p)
     L.faldoi_match_growing_batch.argtypes = [vp, C.c_int, pp, pp, pp, pp, pp, pp, C.c_int, C.c_int, C.c_int,
                                              C.POINTER(LocalParams), pp, pp, C.POINTER(LocalStats)]
@@ -243,6 +246,24 @@ class Context:
         o0, o1 = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
         _check(lib().faldoi_preprocess_local(self._h, i0, i1, w, h, pd, o0, o1))
         return o0, o1
+
+    def tvcsad_global(self, i0n, i1n, u0, xi=None, **params):
+        """Mirror of tvcsad_PD (one-thread stop test).  Returns (u, iters[warps], err[warps], xi, stats)."""
+        i0n, i1n = _f32(i0n), _f32(i1n)
+        h, w = i0n.shape
+        u = _f32(u0).copy()
+        xi = np.zeros((4, h, w), np.float32) if xi is None else _f32(xi).copy()
+        p = Tvl1Params()
+        lib().faldoi_tvcsad_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, "lambda_" if k in ("lambda", "lam") else k, v)
+        its, errs = np.zeros(p.warps, np.int32), np.zeros(p.warps, np.float32)
+        st = Tvl1Stats()
+        st.iters_cap = p.warps
+        st.iters = its.ctypes.data_as(C.POINTER(C.c_int))
+        st.err = errs.ctypes.data_as(C.POINTER(C.c_float))
+        _check(lib().faldoi_tvcsad_global(self._h, i0n, i1n, u, xi.ctypes.data_as(C.c_void_p), w, h, C.byref(p), C.byref(st)))
+        return u, its, errs, xi, st
 
     def fb_consistency_check(self, in0, in1, epsilon=2.0):
         """Mirror of fb_consistency_check: (2,h,w) forward / backward flows -> trust (h,w) int32."""

@@ -149,6 +149,42 @@ __device__ __forceinline__ void sort48(float (&v)[kCsSlots])
     for (int k = 0; k < 384; ++k) cswap(v[kSort48[k].a], v[kSort48[k].b]);
 }
 
+// The CSAD selection shared by NLTV-CSAD (:1733-1758) and TV-CSAD (:1547-1571): returns the element of index
+// n+1 (0-based; `it/2+1` with it = 2n+1, sic) of the ascending sort of
+//   A = { -(b_s - r) : valid s }  united with  B = { (n-2j)*l_t*sg : j = 0..n },
+// b_s = (I0[i] - I0[pos_s] - I1w[i] + I1w[pos_s] + t1 + t2) / sg recomputed from the 7x7 neighbourhoods.
+// A is sorted in registers (invalid slots = +inf); B is an arithmetic progression, so the order statistic
+// is  min over c of max(A_sorted[c-1], B_ascending[n+1-c])  -- the classic two-sorted-arrays split.
+__device__ __forceinline__ float csad_select(const float *__restrict__ I0, const float *__restrict__ I1w, int i, int x, int y,
+                                             int nx, int ny, float t1, float t2, float r, float sg, float l_t)
+{
+    const float i0 = I0[i], i1w = I1w[i];
+    const double rsg = recip_f64(sg);                       // sg >= 1e-4: 48 exact quotients share it
+    float A[kCsSlots];
+    int n = 0, s = 0;
+#pragma unroll
+    for (int k = -kCsR; k <= kCsR; ++k)
+#pragma unroll
+        for (int l = -kCsR; l <= kCsR; ++l) {
+            if (k == 0 && l == 0) continue;
+            const bool valid = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
+            const int pos = valid ? i + k * nx + l : i;
+            const float bs = div_by(i0 - I0[pos] - i1w + I1w[pos] + t1 + t2, sg, rsg);   // :1716-1717 / :1529-1530
+            A[s] = valid ? -(bs - r) : __builtin_inff();            // :1741-1742
+            n += valid ? 1 : 0;
+            ++s;
+        }
+    sort48(A);
+    float m = __builtin_inff();
+#pragma unroll
+    for (int c = 1; c <= kCsSlots; ++c) {                            // c elements taken from A, n+2-c from B
+        // B ascending, index n+1-c  ==  reference's j = c-1:  (n - 2j) * l_t * sg   (:1747)
+        const float bv = (c <= n + 1) ? (float)(n + 2 - 2 * c) * l_t * sg : __builtin_inff();
+        m = __builtin_fminf(m, __builtin_fmaxf(A[c - 1], bv));
+    }
+    return m;
+}
+
 // Data step (:1733-1758) + non-local divergence (:1056-1079) + ofnltv_getP (:1090-1120) + relaxation.
 // The data step needs the element of index n+1 (0-based; `it/2+1` with it = 2n+1, sic) of the
 // ascending sort of  A = { -(b_s - r) : valid s }  united with  B = { (n-2j)*l_t*sg : j = 0..n }.
@@ -172,31 +208,8 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
         const float ixw = base[N_I1WX * pe + i], iyw = base[N_I1WY * pe + i];
         const float sg = __builtin_sqrtf(grad);
         const float r = (ixw * u1k + iyw * u2k) / sg;
-        const float *I0 = base + N_I0 * pe, *I1w = base + N_I1W * pe;
-        const float i0 = I0[i], i1w = I1w[i], t1 = base[N_T1 * pe + i], t2 = base[N_T2 * pe + i];
-        const double rsg = recip_f64(sg);                       // sg >= 1e-4: 48 exact quotients share it
-        float A[kCsSlots];
-        int n = 0, s = 0;
-#pragma unroll
-        for (int k = -kCsR; k <= kCsR; ++k)
-#pragma unroll
-            for (int l = -kCsR; l <= kCsR; ++l) {
-                if (k == 0 && l == 0) continue;
-                const bool valid = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
-                const int pos = valid ? i + k * nx + l : i;
-                const float bs = div_by(i0 - I0[pos] - i1w + I1w[pos] + t1 + t2, sg, rsg);   // :1716-1717
-                A[s] = valid ? -(bs - r) : __builtin_inff();            // :1741-1742
-                n += valid ? 1 : 0;
-                ++s;
-            }
-        sort48(A);
-        float m = __builtin_inff();
-#pragma unroll
-        for (int c = 1; c <= kCsSlots; ++c) {                            // c elements taken from A, n+2-c from B
-            // B ascending, index n+1-c  ==  reference's j = c-1:  (n - 2j) * l_t * sg   (:1747)
-            const float bv = (c <= n + 1) ? (float)(n + 2 - 2 * c) * l_t * sg : __builtin_inff();
-            m = __builtin_fminf(m, __builtin_fmaxf(A[c - 1], bv));
-        }
+        const float m = csad_select(base + N_I0 * pe, base + N_I1W * pe, i, x, y, nx, ny, base[N_T1 * pe + i], base[N_T2 * pe + i],
+                                    r, sg, l_t);
         v1 = u1k - ixw * m / sg;                                         // :1756-1757
         v2 = u2k - iyw * m / sg;
     }
@@ -225,6 +238,126 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
     base[N_U2 * pe + i] = n2;
     base[N_UB1 * pe + i] = 2.0f * n1 - u1k;                              // :1774-1777
     base[N_UB2 * pe + i] = 2.0f * n2 - u2k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TV-CSAD (tvcsad_PD, src/global_faldoi.cpp:1449-1636; global_faldoi -m 4 / 5): the CSAD data term over
+// sg = hypot(Ix^2 + Iy^2, 0.01) with a TV regulariser normalised per flow component (tvcsad_getD :1424).
+// Streams like the solvers above: one launch for the dual step, one for data + divergence + primal step.
+// ---------------------------------------------------------------------------------------------
+enum TcPlane {
+    C_I0 = 0, C_I1, C_I1X, C_I1Y, C_I1W, C_I1WX, C_I1WY, C_GRAD, C_T1, C_T2, C_U1, C_U2, C_UB1, C_UB2,
+    C_X11, C_X12, C_X21, C_X22, C_ERR, C_COUNT
+};
+
+// Per warp (:1509-1538): warps, the two products inside b, ubar = u.  C_GRAD receives Ix^2 + Iy^2; the host
+// replaces it by (float)hypot(that, 0.01) with the C library's double hypot, as the reference computes it.
+__global__ __launch_bounds__(256) void tc_warp_kernel(float *__restrict__ base, size_t pe, int nx, int ny)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= nx * ny) return;
+    const int y = p / nx, x = p - y * nx;
+    const float u1 = base[C_U1 * pe + p], u2 = base[C_U2 * pe + p];
+    const BicubicTaps tp = bicubic_taps((float)x + u1, (float)y + u2, nx, ny);
+    float w0 = 0.0f, wx = 0.0f, wy = 0.0f;
+    if (!tp.clamped) {
+        w0 = bicubic_eval(base + C_I1 * pe, tp, nx);
+        wx = bicubic_eval(base + C_I1X * pe, tp, nx);
+        wy = bicubic_eval(base + C_I1Y * pe, tp, nx);
+    }
+    base[C_I1W * pe + p] = w0;
+    base[C_I1WX * pe + p] = wx;
+    base[C_I1WY * pe + p] = wy;
+    base[C_GRAD * pe + p] = grad_sq(wx, wy);
+    base[C_T1 * pe + p] = wx * u1;
+    base[C_T2 * pe + p] = wy * u2;
+    base[C_UB1 * pe + p] = u1;
+    base[C_UB2 * pe + p] = u2;
+}
+
+// hypotf as the C library evaluates it for finite arguments: sqrt(x*x + y*y) in double, rounded to float
+__device__ __forceinline__ float hypotf_like_libm(float a, float b)
+{
+    if (__builtin_isinf(a) || __builtin_isinf(b)) return __builtin_inff();
+    return (float)__builtin_sqrt((double)a * (double)a + (double)b * (double)b);
+}
+
+// forward_gradient of ubar (src/utils.cpp:285) + tvcsad_getD (:1424-1441)
+__global__ __launch_bounds__(256) void tc_dual_kernel(float *__restrict__ base, size_t pe, int nx, int ny, float tau)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= nx * ny) return;
+    const int y = p / nx, x = p - y * nx;
+    const bool lc = x == nx - 1, lr = y == ny - 1;
+    const float *ub1 = base + C_UB1 * pe, *ub2 = base + C_UB2 * pe;
+    const float a = ub1[p], b = ub2[p];
+    const float ar = ub1[lc ? p : p + 1], ad = ub1[lr ? p : p + nx], br = ub2[lc ? p : p + 1], bd = ub2[lr ? p : p + nx];
+    const float u1x = fwd_diff(ar, a, lc), u1y = fwd_diff(ad, a, lr), u2x = fwd_diff(br, b, lc), u2y = fwd_diff(bd, b, lr);
+    float x11 = base[C_X11 * pe + p], x12 = base[C_X12 * pe + p], x21 = base[C_X21 * pe + p], x22 = base[C_X22 * pe + p];
+    float n1 = hypotf_like_libm(x11, x12), n2 = hypotf_like_libm(x21, x22);
+    n1 = (1 > n1) ? 1 : n1;
+    n2 = (1 > n2) ? 1 : n2;
+    base[C_X11 * pe + p] = (x11 + tau * u1x) / n1;
+    base[C_X12 * pe + p] = (x12 + tau * u1y) / n1;
+    base[C_X21 * pe + p] = (x21 + tau * u2x) / n2;
+    base[C_X22 * pe + p] = (x22 + tau * u2y) / n2;
+}
+
+// Data step (:1547-1571) + divergence (src/utils.cpp:239) + tvcsad_getP (:1386-1414) + relaxation (:1593-1597).
+// The squared update of every pixel goes to C_ERR (the reference's stop test sums them in pixel order) and
+// a per-block double sum to part[] (order-independent to ~1e-13: enough to decide the test whenever the mean
+// is not within the rounding slack of a serial fp32 sum around tol^2; the host settles the rest exactly).
+__global__ __launch_bounds__(256) void tc_primal_kernel(float *__restrict__ base, size_t pe, int nx, int ny, float l_t,
+                                                        float theta, float tau, double *__restrict__ part)
+{
+    __shared__ double red[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float tt = 0.0f;
+    if (i < nx * ny) {
+        const int y = i / nx, x = i - y * nx;
+        const float u1k = base[C_U1 * pe + i], u2k = base[C_U2 * pe + i];
+        const float sg = base[C_GRAD * pe + i];
+        const float ixw = base[C_I1WX * pe + i], iyw = base[C_I1WY * pe + i];
+        const float r = (ixw * u1k + iyw * u2k) / sg;
+        const float m = csad_select(base + C_I0 * pe, base + C_I1W * pe, i, x, y, nx, ny, base[C_T1 * pe + i], base[C_T2 * pe + i],
+                                    r, sg, l_t);
+        const float v1 = u1k - ixw * m / sg;                             // :1568-1569
+        const float v2 = u2k - iyw * m / sg;
+        const PixClass pc = classify(x, y, nx, ny);
+        const float *X11 = base + C_X11 * pe, *X12 = base + C_X12 * pe, *X21 = base + C_X21 * pe, *X22 = base + C_X22 * pe;
+        const int pl = x > 0 ? i - 1 : i, pu = y > 0 ? i - nx : i;
+        const float d1 = div_sample(X11[i], X11[pl], X12[i], X12[pu], pc);
+        const float d2 = div_sample(X21[i], X21[pl], X22[i], X22[pu], pc);
+        const float n1 = u1k - tau * (-d1 + (u1k - v1) / theta);
+        const float n2 = u2k - tau * (-d2 + (u2k - v2) / theta);
+        tt = (n1 - u1k) * (n1 - u1k) + (n2 - u2k) * (n2 - u2k);
+        base[C_U1 * pe + i] = n1;
+        base[C_U2 * pe + i] = n2;
+        base[C_UB1 * pe + i] = 2.0f * n1 - u1k;
+        base[C_UB2 * pe + i] = 2.0f * n2 - u2k;
+        base[C_ERR * pe + i] = tt;
+    }
+    red[threadIdx.x] = (double)tt;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void tc_sum_kernel(const double *__restrict__ part, int nparts, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 256) acc += part[k];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
 }
 
 }  // namespace faldoi

@@ -10,8 +10,8 @@
 // ims.txt: one path per line: I0, I1 [, I-1, I2].  As in the reference, I-1 is only used when
 // the file has four lines, otherwise I1 takes its place in the normalisation (:1933-1937).
 // Methods: 0 (TV-l2 coupled) and 1 (its weighted id, which the reference's global step maps to the
-// same solver, :2132); 2/3 (NLTV-L1, :2145) and 6/7 (NLTV-CSAD, :2137), likewise.  The other
-// functionals are not part of this build and are refused loudly.
+// same solver, :2132); 2/3 (NLTV-L1, :2145), 4/5 (TV-CSAD, :2152) and 6/7 (NLTV-CSAD, :2137), likewise.
+// The occlusion functional (8) is not part of this build and is refused loudly.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -50,10 +50,10 @@ int main(int argc, char *argv[])
         const int gpu = std::stoi(pick_option(args, "gpu", "0"));
         if (args.size() != 4) return usage(args.size());
         const bool tvl1 = method == 0 || method == 1, nltvl1 = method == 2 || method == 3;
-        const bool nltvcsad = method == 6 || method == 7;
-        if (!tvl1 && !nltvcsad && !nltvl1) {
+        const bool nltvcsad = method == 6 || method == 7, tvcsad = method == 4 || method == 5;
+        if (!tvl1 && !nltvcsad && !nltvl1 && !tvcsad) {
             fprintf(stderr, "ERROR: method %d is not available in this build (TV-l2 coupled -m 0/1, NLTV-L1 -m 2/3, "
-                            "NLTV-CSAD -m 6/7)\n", method);
+                            "TV-CSAD -m 4/5, NLTV-CSAD -m 6/7)\n", method);
             return 2;
         }
 
@@ -107,6 +107,25 @@ int main(int argc, char *argv[])
             faldoi_ctx_destroy(c);
             if (rc) return 3;
             write_flo(args[3], u.data(), i0.w, i0.h);
+            return EXIT_SUCCESS;
+        }
+
+        if (tvcsad) {                                      // src/global_faldoi.cpp:2152-2158
+            faldoi_ctx *c = nullptr;
+            if (faldoi_ctx_create(gpu, &c)) { fprintf(stderr, "ERROR: no usable GPU: %s\n", faldoi_last_error()); return 3; }
+            const size_t n = (size_t)i0.w * i0.h;
+            std::vector<float> i0n(n), i1n(n), u(flow.data);
+            int rc = faldoi_preprocess_global(c, i0.data.data(), i1.data.data(), have_im1 ? im1.data.data() : nullptr, i0.w, i0.h,
+                                              pd, i0n.data(), i1n.data());
+            faldoi_tvl1_params tp;                           // lambda/theta/tau are forced (:2153-2155); tol comes from the file
+            faldoi_tvcsad_default_params(&tp);
+            tp.tol = ep.tol; tp.warps = nwarps; tp.max_inner = max_inner; tp.verbose = verbose;
+            if (!rc) rc = faldoi_tvcsad_global(c, i0n.data(), i1n.data(), u.data(), nullptr, i0.w, i0.h, &tp, nullptr);
+            if (rc) fprintf(stderr, "ERROR: %s\n", faldoi_last_error());
+            faldoi_ctx_destroy(c);
+            if (rc) return 3;
+            write_flo(args[3], u.data(), i0.w, i0.h);
+            printf("Exits current level\n");               // :1634
             return EXIT_SUCCESS;
         }
 

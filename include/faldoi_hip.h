@@ -219,6 +219,15 @@ int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, co
 void faldoi_nltvl1_default_params(faldoi_nltvcsad_params *p);
 int faldoi_nltvl1_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd,
                          int nx, int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms);
+
+/* TV-CSAD, tvcsad_PD, src/global_faldoi.cpp:1449-1636 (global_faldoi -m 4 / 5; main forces lambda 0.85, theta 0.3,
+ * tau 0.125, :2153-2156).  Same buffers as tvl2OF: u = 2 planes in/out, xi = 4 planes in/out or NULL (zero).
+ * params: lambda/theta/tau/tol/warps/max_inner/verbose are used (tol_stop, chunk are ignored: the tolerance test
+ * is always on, as in the reference).  The reference accumulates the stop test's mean |du|^2 racily across its
+ * OpenMP threads; this build returns what the reference computes on ONE thread (terms added in pixel order). */
+void faldoi_tvcsad_default_params(faldoi_tvl1_params *p);
+int faldoi_tvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, float *u, float *xi, int nx, int ny,
+                         const faldoi_tvl1_params *params, faldoi_tvl1_stats *stats);
 /* src/global_faldoi.cpp:906-932 image_to_lab: planar R,G,B (0..255) -> planar L,a*,b* (host, libm). */
 int faldoi_image_to_lab(const float *rgb, int nx, int ny, float *lab);
 

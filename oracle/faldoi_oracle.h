@@ -85,6 +85,11 @@ void orc_nltvcsad_global(const float *I0, const float *I1, const float *lab, int
                          float lambda, float theta, float tau, int w, int h, int warps, int max_inner,
                          float *u1, float *u2);
 
+/* TV-CSAD (tvcsad_PD, src/global_faldoi.cpp:1449-1636); xi: 4 planes in/out; returns the total inner iterations */
+long orc_tvcsad_global(const float *I0, const float *I1, float lambda, float theta, float tau, float tol_OF,
+                       int w, int h, int warps, int max_inner, float *u1, float *u2, float *xi,
+                       int *iters_out, float *err_out);
+
 /* ---- local TV-L1 patch operator (faldoi_oracle_local.c; src/tvl2_model.cpp:174-435, src/utils.cpp:63-220) ---- */
 float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x, const float *I1y,
                               float *u1, float *u2, float *state6, int nx, int ny,

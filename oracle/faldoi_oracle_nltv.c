@@ -265,3 +265,113 @@ static void nl_solver(int data_l1, const float *I0, const float *I1, const float
     }
     free(buf);
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * TV-CSAD, tvcsad_PD, src/global_faldoi.cpp:1449-1636 (global_faldoi -m 4 / 5): the CSAD data term of
+ * the NLTV-CSAD solver above over sg = hypot(Ix^2 + Iy^2, 0.01) (double hypot, :1512) with a TV
+ * regulariser whose duals are normalised per flow component with hypotf (:1424-1441), and the stop test
+ * mean |du|^2 > tol^2 (:1540, :1386-1414).
+ * The reference accumulates that mean with `err_D +=` inside an `omp parallel for` without a reduction
+ * clause, i.e. racily; it is deterministic only on one thread, where the terms are added in pixel
+ * order.  That order is what is restated here (the sum runs serially; the rest may use threads).
+ * xi: 4 planes in/out (main zeroes them, :2116-2121); they persist over the warps.
+ * ---------------------------------------------------------------------------------------- */
+long orc_tvcsad_global(const float *I0, const float *I1, float lambda, float theta, float tau, float tol_OF,
+                       int w, int h, int warps, int max_inner, float *u1, float *u2, float *xi,
+                       int *iters_out, float *err_out)
+{
+    const int n = w * h;
+    const float l_t = lambda * theta;
+    float *buf = (float *)calloc((size_t)n * (CS_SLOTS + 18), sizeof(float));
+    float *b = buf;
+    float *I1x = b + (size_t)CS_SLOTS * n, *I1y = I1x + n, *I1w = I1y + n, *I1wx = I1w + n, *I1wy = I1wx + n;
+    float *grad = I1wy + n, *v1 = grad + n, *v2 = v1 + n, *ub1 = v2 + n, *ub2 = ub1 + n;
+    float *u1x = ub2 + n, *u1y = u1x + n, *u2x = u1y + n, *u2y = u2x + n, *dv1 = u2y + n, *dv2 = dv1 + n, *tt = dv2 + n;
+    float *xi11 = xi, *xi12 = xi + n, *xi21 = xi + 2 * (size_t)n, *xi22 = xi + 3 * (size_t)n;
+    long total = 0;
+
+    orc_centered_gradient(I1, I1x, I1y, w, h);                                   /* :1504 */
+    for (int wp_ = 0; wp_ < warps; wp_++) {
+        orc_bicubic_warp(I1, u1, u2, I1w, w, h, 1);                              /* :1509-1511 */
+        orc_bicubic_warp(I1x, u1, u2, I1wx, w, h, 1);
+        orc_bicubic_warp(I1y, u1, u2, I1wy, w, h, 1);
+#pragma omp parallel for
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const int i = y * w + x;
+                const float Ix2 = I1wx[i] * I1wx[i], Iy2 = I1wy[i] * I1wy[i];
+                grad[i] = (float)hypot(Ix2 + Iy2, 0.01);                         /* :1518 */
+                int s = 0;
+                for (int k = -CS_R; k <= CS_R; k++)
+                    for (int l = -CS_R; l <= CS_R; l++) {
+                        if (k == 0 && l == 0) continue;
+                        if (x + l >= 0 && x + l < w && y + k >= 0 && y + k < h) {
+                            const int pos = (y + k) * w + (x + l);
+                            b[(size_t)s * n + i] = (I0[i] - I0[pos] - I1w[i] + I1w[pos] + I1wx[i] * u1[i]
+                                                    + I1wy[i] * u2[i]) / grad[i];   /* :1529-1530 */
+                        }
+                        s++;
+                    }
+                ub1[i] = u1[i];                                                  /* :1535-1538 */
+                ub2[i] = u2[i];
+            }
+        int it_n = 0;
+        float err_D = INFINITY;
+        while (err_D > tol_OF * tol_OF && it_n < max_inner) {                    /* :1542 */
+            it_n++;
+#pragma omp parallel for
+            for (int y = 0; y < h; y++) {                                        /* :1547-1571 */
+                float ba[2 * CS_SLOTS + 1];
+                for (int x = 0; x < w; x++) {
+                    const int i = y * w + x;
+                    int it = 0, s = 0, nn = 0;
+                    for (int k = -CS_R; k <= CS_R; k++)
+                        for (int l = -CS_R; l <= CS_R; l++) {
+                            if (k == 0 && l == 0) continue;
+                            if (x + l >= 0 && x + l < w && y + k >= 0 && y + k < h) {
+                                ba[it++] = -(b[(size_t)s * n + i] - (I1wx[i] * u1[i] + I1wy[i] * u2[i]) / grad[i]);
+                                nn++;
+                            }
+                            s++;
+                        }
+                    for (int j = 0; j < nn + 1; j++) ba[it++] = (nn - 2 * j) * l_t * grad[i];
+                    qsort(ba, (size_t)it, sizeof(float), cmp_float);
+                    v1[i] = u1[i] - I1wx[i] * ba[it / 2 + 1] / grad[i];          /* :1568-1569, sic */
+                    v2[i] = u2[i] - I1wy[i] * ba[it / 2 + 1] / grad[i];
+                }
+            }
+            orc_forward_gradient(ub1, u1x, u1y, w, h);                           /* :1576-1578 */
+            orc_forward_gradient(ub2, u2x, u2y, w, h);
+#pragma omp parallel for
+            for (int i = 0; i < n; i++) {                                        /* tvcsad_getD :1424-1441 */
+                float n1 = hypotf(xi11[i], xi12[i]), n2 = hypotf(xi21[i], xi22[i]);
+                n1 = (1 > n1) ? 1 : n1;
+                n2 = (1 > n2) ? 1 : n2;
+                xi11[i] = (xi11[i] + tau * u1x[i]) / n1;
+                xi12[i] = (xi12[i] + tau * u1y[i]) / n1;
+                xi21[i] = (xi21[i] + tau * u2x[i]) / n2;
+                xi22[i] = (xi22[i] + tau * u2y[i]) / n2;
+            }
+            orc_divergence(xi11, xi12, dv1, w, h);                               /* :1581-1582 */
+            orc_divergence(xi21, xi22, dv2, w, h);
+#pragma omp parallel for
+            for (int i = 0; i < n; i++) {                                        /* tvcsad_getP :1386-1414 + :1593-1597 */
+                const float u1k = u1[i], u2k = u2[i];
+                u1[i] = u1k - tau * (-dv1[i] + (u1k - v1[i]) / theta);
+                u2[i] = u2k - tau * (-dv2[i] + (u2k - v2[i]) / theta);
+                tt[i] = (u1[i] - u1k) * (u1[i] - u1k) + (u2[i] - u2k) * (u2[i] - u2k);
+                ub1[i] = 2 * u1[i] - u1k;
+                ub2[i] = 2 * u2[i] - u2k;
+            }
+            err_D = 0.0f;
+            for (int i = 0; i < n; i++) err_D += tt[i];                          /* one thread: pixel order */
+            err_D /= n;
+        }
+        if (iters_out) iters_out[wp_] = it_n;
+        if (err_out) err_out[wp_] = err_D;
+        total += it_n;
+    }
+    free(buf);
+    return total;
+}

@@ -93,6 +93,8 @@ def lib():
         L.orc_nltvcsad_global.argtypes = [_F, _F, _F, C.c_int, C.c_float, C.c_float, C.c_float,
                                           C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]
         L.orc_nltvl1_global.argtypes = L.orc_nltvcsad_global.argtypes
+        L.orc_tvcsad_global.argtypes = [_F, _F] + [C.c_float] * 4 + [C.c_int] * 4 + [_F, _F, _F, _I, _F]
+        L.orc_tvcsad_global.restype = C.c_long
         L.orc_elap_recursive.argtypes = [_F, _F, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
         L.orc_interpolate_poisson.argtypes = [_F, _F, _I, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_local_tvl1_estimate.argtypes = [_F] * 7 + [C.c_int] * 7 + [C.POINTER(C.c_int)]
@@ -279,3 +281,14 @@ def local_faldoi(i0n, i1n, go, ba, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2
     ptr = [k.ctypes.data if k is not None else None for k in keep]
     lib().orc_local_faldoi(i0n, i1n, go, ba, ptr[0], ptr[1], w, h, wr, loc_it, max_iter_patch, fb_thresh, out, ene, st)
     return out, ene, st
+
+
+def tvcsad_global(i0n, i1n, u0, lam=0.85, theta=0.3, tau=0.125, tol=0.01, warps=5, max_inner=400, xi=None):
+    """tvcsad_PD with the reference's one-thread stop test.  Returns (u, iters[warps], err[warps], xi)."""
+    i0n, i1n = f32(i0n), f32(i1n)
+    h, w = i0n.shape
+    u = f32(u0).copy()
+    xi = np.zeros((4, h, w), np.float32) if xi is None else f32(xi).copy()
+    its, errs = np.zeros(warps, np.int32), np.zeros(warps, np.float32)
+    lib().orc_tvcsad_global(i0n, i1n, lam, theta, tau, tol, w, h, warps, max_inner, u[0], u[1], xi, its, errs)
+    return u, its, errs, xi

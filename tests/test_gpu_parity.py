@@ -640,3 +640,46 @@ def test_fb_consistency_check_at_the_threshold(ctx, oracle):
     go[:, 20:22, 30:33] = np.nan
     oracle.lib().orc_fb_consistency_check(go, ba, trust, w, h, 2.0)
     assert np.array_equal(ctx.fb_consistency_check(go, ba, 2.0), trust)
+
+
+@pytest.mark.parametrize("crop,warps,tol", [((400, 150, 96, 64), 3, 0.01), ((30, 20, 61, 45), 2, 0.02)])
+def test_tvcsad_bit_exact(ctx, oracle, crop, warps, tol):
+    # TV-CSAD (method 4): CSAD data term + TV regulariser, stop test = the reference's one-thread serial mean
+    i0, i1 = sintel_pair(crop)
+    a, b = oracle.preprocess_global(i0, i1, None)
+    u0 = np.zeros((2,) + a.shape, np.float32)
+    want, wits, werr, wxi = oracle.tvcsad_global(a, b, u0, warps=warps, tol=tol, max_inner=150)
+    got, gits, gerr, gxi, st = ctx.tvcsad_global(a, b, u0, warps=warps, tol=tol, max_inner=150)
+    assert list(gits) == list(wits), (gits, wits)
+    assert bits_equal(got, want), mismatch_report(got, want)
+    assert bits_equal(gxi, wxi)
+    assert min(wits) < 150                 # at least one warp ends through the tolerance test
+    # the fast decision (order-independent double sum outside the rounding band) and the reference's serial
+    # fp32 sum must agree: force the serial path for every stop test and compare
+    import os
+    os.environ["FALDOI_TVCSAD_SERIAL_SUM"] = "1"
+    try:
+        got2, gits2, gerr2, _, st2 = ctx.tvcsad_global(a, b, u0, warps=warps, tol=tol, max_inner=150)
+    finally:
+        os.environ.pop("FALDOI_TVCSAD_SERIAL_SUM")
+    assert st2.chunk_launches == int(gits2.sum()) and list(gits2) == list(wits)
+    assert bits_equal(got2, want) and np.array_equal(gerr2.view(np.uint32), werr.view(np.uint32))
+
+
+def test_global_faldoi_cli_method4_matches_cpu_path(oracle, tmp_path):
+    # `global_faldoi ims.txt zero.flo out.flo -m 4 -w 2` (TV-CSAD) on a crop against the CPU path
+    from PIL import Image
+    i0, i1 = sintel_pair((420, 160, 80, 56))
+    h, w = i0.shape[1:]
+    for k, im in enumerate((i0, i1)):
+        Image.fromarray(im.transpose(1, 2, 0).astype(np.uint8), "RGB").save(tmp_path / ("c%d.png" % k))
+    (tmp_path / "ims.txt").write_text("%s\n%s\n" % (tmp_path / "c0.png", tmp_path / "c1.png"))
+    F.flo.write_flo(str(tmp_path / "zero.flo"), np.zeros((2, h, w), np.float32))
+    bins = F.build.build_host()
+    r = subprocess.run([bins["global_faldoi"], str(tmp_path / "ims.txt"), str(tmp_path / "zero.flo"), str(tmp_path / "out.flo"),
+                        "-m", "4", "-w", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    a, b = oracle.preprocess_global(i0, i1, None)
+    want, _, _, _ = oracle.tvcsad_global(a, b, np.zeros((2, h, w), np.float32), warps=2)
+    got = F.flo.read_flo(str(tmp_path / "out.flo"))
+    assert bits_equal(got, want), mismatch_report(got, want)

@@ -90,7 +90,7 @@ def test_global_faldoi_cli_argument_handling(bins, tmp_path):
     z = tmp_path / "zero.flo"
     F.flo.write_flo(str(z), np.zeros((2, 436, 1024), np.float32))
     # option pairs may sit anywhere; unsupported functionals are refused, not silently replaced
-    r = subprocess.run([exe, "-m", "4", str(ims), str(z), str(tmp_path / "o.flo")], capture_output=True, text=True)
+    r = subprocess.run([exe, "-m", "8", str(ims), str(z), str(tmp_path / "o.flo")], capture_output=True, text=True)
     assert r.returncode == 2 and "not available" in r.stderr
     small = tmp_path / "small.flo"
     F.flo.write_flo(str(small), np.zeros((2, 4, 4), np.float32))
