@@ -41,6 +41,7 @@ struct GrowDir {                      // per growing: device pointers (array in 
     float *ene;                       // ene_Go / ene_Ba
     float *out;                       // oft0 / oft1: [2][pe]
     const float *sal;                 // saliency or nullptr (= 1)
+    const float *weight;              // gaussian1Dweight(w_radio) for the weighted functional (-m 1), else nullptr
     Candidate *heap;
     GrowCtl *ctl;
     const int *seeds;                 // pixel indices of the finite seeds, row-major order
@@ -232,15 +233,26 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
 // the image border -- keep their HBM value, as in the reference.
 // Thread 0 returns the window energy; every thread returns its new (u1, u2) in place.
 // ---------------------------------------------------------------------------------------------
+// weight != nullptr: the weighted functional, guided_tvl2coupled_w (src/tvl2w_model.cpp:254-455): l_t is scaled per
+// pixel by weight[row] * weight[column] (:379), lambda is divided by weight[w_radio + 1]^2 with the radius in force
+// during the call (src/energy_model.cpp:744-745), and the data energy is weighted (:227, a double product).
 __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_t pe, int nx, int ny, int ii, int ij, int ei,
-                                              int ej, int max_iter_patch, float &u1, float &u2)
+                                              int ej, int max_iter_patch, float &u1, float &u2, const float *weight, int iiw,
+                                              int ijw, int wr_call)
 {
     const int pw = ei - ii, ph = ej - ij, t = threadIdx.x;
     const bool act = t < pw * ph;
     const int k = ii + (act ? t % pw : 0), l = ij + (act ? t / pw : 0);
     const int p = l * nx + k;
-    const float lambda = 40.0f, theta = 0.3f, tau = 0.125f, tol_OF = 0.01f;        // src/energy_model.cpp:704-709
-    const float l_t = lambda * theta;
+    const float theta = 0.3f, tau = 0.125f, tol_OF = 0.01f;                       // src/energy_model.cpp:704-709
+    float lambda = 40.0f, gwy = 1.0f, gwx = 1.0f;
+    if (weight) {
+        const float central = weight[wr_call + 1];
+        lambda = lambda / (central * central);
+        gwy = weight[l - ij + ijw];
+        gwx = weight[k - ii + iiw];
+    }
+    const float l_t = weight ? lambda * theta * gwy * gwx : lambda * theta;
     const float *I0 = base + L_I0 * pe, *I1 = base + L_I1 * pe, *I1x = base + L_I1X * pe, *I1y = base + L_I1Y * pe;
     float *D1 = base + L_DIV1 * pe, *D2 = base + L_DIV2 * pe;
 
@@ -345,7 +357,8 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         const float u2x = !last_col ? br - u2 : 0.0f, u2y = !last_row ? bd - u2 : 0.0f;
         const BicubicTaps tp = bicubic_taps((float)k + u1, (float)l + u2, nx, ny);
         const float iw = bicubic_eval(I1, tp, nx);
-        const float dt = lambda * __builtin_fabsf(iw - i0);
+        const float dt = weight ? (float)((double)lambda * __builtin_fabs((double)(iw - i0)) * (double)gwy * (double)gwx)
+                                : lambda * __builtin_fabsf(iw - i0);
         const float dc = (1 / (2 * theta)) * ((u1 - v1) * (u1 - v1) + (u2 - v2) * (u2 - v2));
         const float g = __builtin_sqrtf(u1x * u1x + u1y * u1y + u2x * u2x + u2y * u2y);
         term = dc + dt + g;
@@ -507,7 +520,8 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
         u2 = D.planes[L_U2 * pe + p];
     }
     const long long c1 = clock64();
-    const float ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2);
+    const int iiw = (i - wr < 0) ? -(i - wr) : 0, ijw = (j - wr < 0) ? -(j - wr) : 0;    // get_relative_index_weight :551-557
+    const float ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2, D.weight, iiw, ijw, wr);
     const long long c2 = clock64();
     if (t == 0) {                                                                 // insert_candidates :497-537
 #pragma unroll

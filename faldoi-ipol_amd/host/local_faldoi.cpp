@@ -13,7 +13,7 @@
 // image under a name it has no encoder for: ASCII "P2" with one C99 hex-float per line
 // (src/iio.c:3505-3511).  Like the reference, the local step ignores the values of
 // the -p file (src/energy_model.cpp:704-709).
-// Built: -m 0 (TV-l2 coupled), -split_img 0.  Other functionals / partitioning are refused loudly.
+// Built: -m 0 (TV-l2 coupled) and -m 1 (TV-l2 coupled with weights), -split_img 0.  Other functionals / partitioning are refused loudly.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -74,8 +74,9 @@ int main(int argc, char *argv[])
             fprintf(stderr, "ERROR: the occlusion outputs (TV-l1 with occlusions, -m 8) are not part of this build\n");
             return 2;
         }
-        if (method != 0) {
-            fprintf(stderr, "ERROR: method %d is not available in the local step of this build (TV-l2 coupled, -m 0)\n", method);
+        if (method != 0 && method != 1) {
+            fprintf(stderr, "ERROR: method %d is not available in the local step of this build (TV-l2 coupled -m 0, with "
+                            "weights -m 1)\n", method);
             return 2;
         }
         if (split_img != 0) { fprintf(stderr, "ERROR: image partitioning (-split_img 1) is not part of this build\n"); return 2; }
@@ -127,7 +128,7 @@ int main(int argc, char *argv[])
         faldoi_local_params prm;
         faldoi_local_default_params(&prm);
         prm.w_radio = w_radio; prm.iterations_of = loc_it; prm.max_iter_patch = max_pch_it; prm.epsilon = fb_thresh;
-        prm.verbose = verbose;
+        prm.verbose = verbose; prm.method = method;
         if (budget > 0) prm.budget = budget;
         faldoi_ctx *ctx = nullptr;
         if (faldoi_ctx_create(gpu, &ctx)) { fprintf(stderr, "ERROR: no usable GPU: %s\n", faldoi_last_error()); return 3; }

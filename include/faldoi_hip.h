@@ -247,6 +247,7 @@ typedef struct faldoi_local_params {
     int preprocessed;     /* extension: 1 = i0/i1 are normalised gray planes (skip prepare_stuff's image part) */
     int budget;           /* windows per growing per kernel launch (host relaunches until the queue is empty) */
     int verbose;
+    int method;           /* -m: 0 = TV-l2 coupled (M_TVL1), 1 = TV-l2 coupled with weights (M_TVL1_W, src/tvl2w_model.cpp) */
 } faldoi_local_params;
 typedef struct faldoi_local_stats {
     long long pops[2];    /* candidates popped, forward / backward (summed over the batch) */

@@ -95,6 +95,12 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
                               float *u1, float *u2, float *state6, int nx, int ny,
                               int ii, int ij, int ei, int ej, int max_iter_patch, int *iters_out);
 
+void orc_gaussian1d_weight(float *I, int r);
+float orc_local_tvl1w_estimate(const float *I0, const float *I1, const float *I1x, const float *I1y,
+                               float *u1, float *u2, float *state6, int nx, int ny,
+                               int ii, int ij, int ei, int ej, int max_iter_patch, int *iters_out,
+                               const float *weight, int iiw, int ijw, int wr_call);
+
 /* src/elap_recsep.c:193-231 and interpolate_poisson, src/local_faldoi.cpp:326-372 */
 void orc_elap_recursive(float *out, const float *in, int w, int h, float timestep, int niter, int scale);
 void orc_interpolate_poisson(float *u1, float *u2, const int *fixed_points, int nx, int ii, int ij, int ei, int ej);
@@ -103,7 +109,7 @@ void orc_interpolate_poisson(float *u1, float *u2, const int *fixed_points, int 
 void orc_preprocess_local(const float *i0, const float *i1, int w, int h, int pd, float *i0n, float *i1n);
 void orc_local_faldoi(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,
                       const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
-                      float *out_flow, float *ene_val, long *stats);
+                      int method, float *out_flow, float *ene_val, long *stats);
 double orc_fb_consistency_check(const float *in0, const float *in1, int *trust, int w, int h, float epsilon);
 void *orc_queue_new(void);
 void orc_queue_free(void *q);

@@ -46,6 +46,8 @@ struct Direction {                 // OpticalFlowData + Tvl2CoupledOFStuff + the
     CandidateQueue queue;
     long pops, solves, fills;
     int max_iter_patch, wr;
+    int method;                    // 0: TV-l2 coupled, 1: with weights (M_TVL1_W)
+    std::vector<float> weight;     // gaussian1Dweight(params.w_radio), prepare_stuff src/energy_model.cpp:429-436
 };
 
 struct Window { int ii, ij, ei, ej; };
@@ -80,8 +82,15 @@ void add_neighbors(Direction &d, int i, int j, int iteration, int wr)
         orc_interpolate_poisson(u1, u2, d.fixed.data(), w, x.ii, x.ij, x.ei, x.ej);
         d.fills++;
     }
-    const float ener = orc_local_tvl1_estimate(d.src, d.dst, d.dstx.data(), d.dsty.data(), u1, u2, d.state.data(), w, h,
-                                               x.ii, x.ij, x.ei, x.ej, d.max_iter_patch, NULL);
+    float ener;
+    if (d.method == 1) {                                                 // get_index_weight :571-597 with this call's radius
+        const int iiw = (i - wr < 0) ? -(i - wr) : 0, ijw = (j - wr < 0) ? -(j - wr) : 0;
+        ener = orc_local_tvl1w_estimate(d.src, d.dst, d.dstx.data(), d.dsty.data(), u1, u2, d.state.data(), w, h, x.ii, x.ij, x.ei,
+                                        x.ej, d.max_iter_patch, NULL, d.weight.data(), iiw, ijw, wr);
+    } else {
+        ener = orc_local_tvl1_estimate(d.src, d.dst, d.dstx.data(), d.dsty.data(), u1, u2, d.state.data(), w, h, x.ii, x.ij, x.ei,
+                                       x.ej, d.max_iter_patch, NULL);
+    }
     d.solves++;
     static const int nb[4][2] = { { 0, 1 }, { 0, -1 }, { 1, 0 }, { -1, 0 } };   // insert_candidates :497-537
     for (int k = 0; k < 4; k++) {
@@ -199,8 +208,11 @@ void insert_potential_candidates(Direction &d)                           // :813
 }
 
 void init_direction(Direction &d, const float *src, const float *dst, const float *sal, int w, int h, int wr,
-                    int max_iter_patch)
+                    int max_iter_patch, int method)
 {
+    d.method = method;
+    d.weight.assign(2 * wr + 1, 0.0f);
+    orc_gaussian1d_weight(d.weight.data(), wr);
     const size_t n = (size_t)w * h;
     d.w = w; d.h = h; d.src = src; d.dst = dst; d.sal = sal; d.wr = wr; d.max_iter_patch = max_iter_patch;
     d.dstx.assign(n, 0.0f); d.dsty.assign(n, 0.0f);
@@ -243,12 +255,12 @@ extern "C" double orc_fb_consistency_check(const float *in0, const float *in1, i
  * stats (may be NULL): [0..2] forward pops / patch solves / Poisson fills, [3..5] backward. */
 extern "C" void orc_local_faldoi(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,
                                  const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
-                                 float *out_flow, float *ene_val, long *stats)
+                                 int method, float *out_flow, float *ene_val, long *stats)
 {
     const size_t n = (size_t)w * h;
     Direction d[2];
-    init_direction(d[0], i0n, i1n, sal0, w, h, wr, max_iter_patch);
-    init_direction(d[1], i1n, i0n, sal1, w, h, wr, max_iter_patch);
+    init_direction(d[0], i0n, i1n, sal0, w, h, wr, max_iter_patch, method);
+    init_direction(d[1], i1n, i0n, sal1, w, h, wr, max_iter_patch, method);
 #pragma omp parallel for num_threads(2)
     for (int k = 0; k < 2; k++) insert_initial_seeds(d[k], k == 0 ? go : ba);     // :1130-1139
     for (int it = 0; it < loc_it; it++) {                                          // :1184-1282

@@ -58,11 +58,50 @@ static void div_patch(const float *v1, const float *v2, float *div, int ii, int 
 /* One call of of_estimation (TV-l2 coupled).  I1x/I1y = centred gradient of I1 (prepare_stuff).
  * u1,u2: full planes, updated inside the window.  st: 6*nx*ny persistent floats.  Returns the
  * patch energy (*ener_N of the reference); *iters_out = inner iterations run. */
+static float local_estimate(const float *I0, const float *I1, const float *I1x, const float *I1y,
+                            float *u1, float *u2, float *st, int nx, int ny,
+                            int ii, int ij, int ei, int ej, int max_iter_patch, int *iters_out,
+                            const float *weight, int iiw, int ijw, float lambda);
+
 float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x, const float *I1y,
                               float *u1, float *u2, float *st, int nx, int ny,
                               int ii, int ij, int ei, int ej, int max_iter_patch, int *iters_out)
 {
-    const float lambda = 40, theta = 0.3f, tau = 0.125f, tol_OF = 0.01f;   /* src/energy_model.cpp:704-709 */
+    return local_estimate(I0, I1, I1x, I1y, u1, u2, st, nx, ny, ii, ij, ei, ej, max_iter_patch, iters_out, NULL, 0, 0, 40);
+}
+
+/* gaussian1Dweight, src/utils.cpp:633-651 (C++: exp of a float argument is expf) */
+void orc_gaussian1d_weight(float *I, int r)
+{
+    const float sigma = r * 0.3333;
+    const float den = 2 * sigma * sigma;
+    for (int i = 0; i < 2 * r + 1; i++)
+        I[i] = (float)(1 / (sigma * sqrt(2.0 * 3.1415926)) * expf(-(i - r) * (i - r) / den));
+}
+
+/* The weighted functional (-m 1): of_estimation's M_TVL1_W branch (src/energy_model.cpp:742-749) =
+ * guided_tvl2coupled_w (src/tvl2w_model.cpp:254-455) + eval_tvl2coupled_w (:173-250).  Same iteration as above
+ * with l_t scaled per pixel by weight[row]*weight[column] (:379) and the data energy weighted (:227);
+ * weight: gaussian1Dweight of the configured radius; iiw/ijw: get_relative_index_weight
+ * (src/local_faldoi.cpp:551-557) for the radius of this call; wr_call: that radius (the reference divides lambda
+ * by weight[w_radio + 1]^2 with the w_radio in force during the call, :744-745). */
+float orc_local_tvl1w_estimate(const float *I0, const float *I1, const float *I1x, const float *I1y,
+                               float *u1, float *u2, float *st, int nx, int ny,
+                               int ii, int ij, int ei, int ej, int max_iter_patch, int *iters_out,
+                               const float *weight, int iiw, int ijw, int wr_call)
+{
+    const float central = weight[wr_call + 1];
+    const float lambda = 40.0f / (central * central);
+    return local_estimate(I0, I1, I1x, I1y, u1, u2, st, nx, ny, ii, ij, ei, ej, max_iter_patch, iters_out, weight, iiw, ijw,
+                          lambda);
+}
+
+static float local_estimate(const float *I0, const float *I1, const float *I1x, const float *I1y,
+                            float *u1, float *u2, float *st, int nx, int ny,
+                            int ii, int ij, int ei, int ej, int max_iter_patch, int *iters_out,
+                            const float *weight, int iiw, int ijw, float lambda)
+{
+    const float theta = 0.3f, tau = 0.125f, tol_OF = 0.01f;                /* src/energy_model.cpp:704-709 */
     const float l_t = lambda * theta;
     const size_t n = (size_t)nx * ny;
     float *xi11 = st, *xi12 = st + n, *xi21 = st + 2 * n, *xi22 = st + 3 * n, *div1 = st + 4 * n, *div2 = st + 5 * n;
@@ -107,9 +146,10 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
             for (int k = ii; k < ei; k++) {
                 const int i = l * nx + k;
                 const float rho = rho_c[i] + (I1wx[i] * u1[i] + I1wy[i] * u2[i]);
+                const float l_t_w = weight ? l_t * weight[l - ij + ijw] * weight[k - ii + iiw] : l_t;   /* tvl2w :379 */
                 float d1, d2;
-                if (rho < -l_t * grad[i]) { d1 = l_t * I1wx[i]; d2 = l_t * I1wy[i]; }
-                else if (rho > l_t * grad[i]) { d1 = -l_t * I1wx[i]; d2 = -l_t * I1wy[i]; }
+                if (rho < -l_t_w * grad[i]) { d1 = l_t_w * I1wx[i]; d2 = l_t_w * I1wy[i]; }
+                else if (rho > l_t_w * grad[i]) { d1 = -l_t_w * I1wx[i]; d2 = -l_t_w * I1wy[i]; }
                 else if (grad[i] < 1E-8) { d1 = d2 = 0; }
                 else { const float fi = -rho / grad[i]; d1 = fi * I1wx[i]; d2 = fi * I1wy[i]; }
                 v1[i] = u1[i] + d1;
@@ -155,7 +195,10 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
         for (int k = ii; k < ei; k++) {
             const int i = l * nx + k;
             const float iw = orc_bicubic_at(I1, (float)k + u1[i], (float)l + u2[i], nx, ny, 0);
-            const float dt = lambda * fabsf(iw - I0[i]);
+            /* `fabs` resolves to the double function there, so the weighted product (tvl2w :227) runs in double
+             * and is rounded once; without weights the single product rounds the same either way */
+            const float dt = weight ? (float)((double)lambda * fabs((double)(iw - I0[i])) * weight[l - ij + ijw] * weight[k - ii + iiw])
+                                    : lambda * fabsf(iw - I0[i]);
             const float dc = (1 / (2 * theta)) * ((u1[i] - v1[i]) * (u1[i] - v1[i]) + (u2[i] - v2[i]) * (u2[i] - v2[i]));
             const float g1 = u1x[i] * u1x[i], g12 = u1y[i] * u1y[i], g21 = u2x[i] * u2x[i], g2 = u2y[i] * u2y[i];
             const float g = sqrtf(g1 + g12 + g21 + g2);

@@ -101,7 +101,10 @@ def lib():
         L.orc_local_tvl1_estimate.restype = C.c_float
         _FN = C.c_void_p                         # float plane or NULL
         L.orc_preprocess_local.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, _F, _F]
-        L.orc_local_faldoi.argtypes = [_F, _F, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float, _F, _F,
+        L.orc_gaussian1d_weight.argtypes = [_F, C.c_int]
+        L.orc_local_tvl1w_estimate.argtypes = [_F] * 7 + [C.c_int] * 7 + [C.POINTER(C.c_int), _F, C.c_int, C.c_int, C.c_int]
+        L.orc_local_tvl1w_estimate.restype = C.c_float
+        L.orc_local_faldoi.argtypes = [_F, _F, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float, C.c_int, _F, _F,
                                        np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
         L.orc_fb_consistency_check.argtypes = [_F, _F, _I, C.c_int, C.c_int, C.c_float]
         L.orc_fb_consistency_check.restype = C.c_double
@@ -142,6 +145,13 @@ def ref():
             R.ref_local_tvl1_div.argtypes = [C.c_void_p, C.c_int]
             R.ref_local_tvl1_div.restype = C.POINTER(C.c_float)
         if hasattr(R, "ref_elap_recursive_separable"):
+            if hasattr(R, "ref_local_tvl1w_create"):
+                R.ref_local_tvl1w_create.restype = C.c_void_p
+                R.ref_local_tvl1w_create.argtypes = [C.c_int, C.c_int, C.c_int]
+                R.ref_local_tvl1w_destroy.argtypes = [C.c_void_p]
+                R.ref_local_tvl1w_estimate.restype = C.c_float
+                R.ref_local_tvl1w_estimate.argtypes = [C.c_void_p, _F, _F, _F, _F, _F, _F] + [C.c_int] * 8
+                R.ref_gaussian1d_weight.argtypes = [_F, C.c_int]
             R.ref_elap_recursive_separable.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
         if hasattr(R, "ref_zoom_out"):
             R.ref_zoom_size.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_float]
@@ -271,7 +281,7 @@ def preprocess_local(i0, i1):
     return a, b
 
 
-def local_faldoi(i0n, i1n, go, ba, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2.0, sal0=None, sal1=None):
+def local_faldoi(i0n, i1n, go, ba, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2.0, sal0=None, sal1=None, method=0):
     """match_growing_variational (-m 0, no partitions).  go/ba: (2,h,w) seed flows, NaN = no seed.
     Returns (out_flow (2,h,w), ene_val (h,w), stats[6])."""
     i0n, i1n, go, ba = f32(i0n), f32(i1n), f32(go), f32(ba)
@@ -279,7 +289,7 @@ def local_faldoi(i0n, i1n, go, ba, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2
     out, ene, st = np.empty((2, h, w), np.float32), np.empty((h, w), np.float32), np.zeros(6, np.int64)
     keep = [f32(s) if s is not None else None for s in (sal0, sal1)]
     ptr = [k.ctypes.data if k is not None else None for k in keep]
-    lib().orc_local_faldoi(i0n, i1n, go, ba, ptr[0], ptr[1], w, h, wr, loc_it, max_iter_patch, fb_thresh, out, ene, st)
+    lib().orc_local_faldoi(i0n, i1n, go, ba, ptr[0], ptr[1], w, h, wr, loc_it, max_iter_patch, fb_thresh, method, out, ene, st)
     return out, ene, st
 
 

@@ -8,6 +8,7 @@
 #include <cstring>
 #include "utils.h"                       // reference: src/utils.h
 #include "tvl2_model.h"                  // reference: src/tvl2_model.h (guided_tvl2coupled)
+#include "tvl2w_model.h"                 // reference: src/tvl2w_model.h (guided_tvl2coupled_w)
 extern "C" {
 #include "bicubic_interpolation.h"       // reference: src/bicubic_interpolation.h
 #include "zoom.h"                        // reference: src/zoom.h (zoom.c is compiled with mask.c, as it includes mask.h)
@@ -108,6 +109,61 @@ const float *ref_local_tvl1_div(void *h, int which)
 {
     RefLocal *r = (RefLocal *)h;
     return which ? r->stuff.tvl2.div_xi2 : r->stuff.tvl2.div_xi1;
+}
+
+// ---- the weighted functional: the reference's guided_tvl2coupled_w (src/tvl2w_model.cpp:254) the way
+// of_estimation calls it (src/energy_model.cpp:742-749), weights from its gaussian1Dweight (src/utils.cpp:633)
+struct RefLocalW {
+    SpecificOFStuff stuff;
+    OpticalFlowData ofd;
+    int w, h, wr;
+};
+
+void ref_gaussian1d_weight(float *I, int r) { gaussian1Dweight(I, r); }
+
+void *ref_local_tvl1w_create(int w, int h, int wr)
+{
+    RefLocalW *r = new RefLocalW();
+    r->w = w; r->h = h; r->wr = wr;
+    memset(&r->ofd, 0, sizeof(OpticalFlowData));
+    r->ofd.params.w_radio = wr;
+    initialize_stuff_tvl2coupled_w(&r->stuff, &r->ofd, w, h);
+    Tvl2CoupledOFStuff_W &t = r->stuff.tvl2w;
+    float *planes[] = {t.xi11, t.xi12, t.xi21, t.xi22, t.u1x, t.u1y, t.u2x, t.u2y, t.v1, t.v2, t.rho_c, t.grad,
+                       t.u1_, t.u2_, t.u1Aux, t.u2Aux, t.I1x, t.I1y, t.I1w, t.I1wx, t.I1wy, t.div_xi1, t.div_xi2, t.u_N};
+    for (float *p : planes) memset(p, 0, sizeof(float) * (size_t)w * h);
+    gaussian1Dweight(t.weight, wr);                                  // prepare_stuff, src/energy_model.cpp:432-435
+    return r;
+}
+
+void ref_local_tvl1w_destroy(void *h)
+{
+    RefLocalW *r = (RefLocalW *)h;
+    free_stuff_tvl2coupled_w(&r->stuff);
+    delete r;
+}
+
+// wr_call: the radius in force during the call (1 for the seeds); iiw/ijw as get_index_weight sets them
+float ref_local_tvl1w_estimate(void *h, const float *I0, const float *I1, const float *I1x, const float *I1y,
+                               float *u1, float *u2, int ii, int ij, int ei, int ej, int max_iter_patch, int iiw, int ijw,
+                               int wr_call)
+{
+    RefLocalW *r = (RefLocalW *)h;
+    const size_t n = (size_t)r->w * r->h;
+    Tvl2CoupledOFStuff_W &t = r->stuff.tvl2w;
+    memcpy(t.I1x, I1x, sizeof(float) * n);
+    memcpy(t.I1y, I1y, sizeof(float) * n);
+    t.iiw = iiw;
+    t.ijw = ijw;
+    r->ofd.u1 = u1;
+    r->ofd.u2 = u2;
+    r->ofd.params.max_iter_patch = max_iter_patch;
+    float lambda = 40;                                               // src/energy_model.cpp:704, :744-745
+    const float central = t.weight[wr_call + 1];
+    lambda = lambda / (central * central);
+    float ener = 0.f;
+    guided_tvl2coupled_w(I0, I1, &r->ofd, &t, &ener, ii, ij, ei, ej, lambda, 0.3, 0.125, 0.01, 1, false, r->w, r->h);
+    return ener;
 }
 
 }  // extern "C"

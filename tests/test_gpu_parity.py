@@ -683,3 +683,17 @@ def test_global_faldoi_cli_method4_matches_cpu_path(oracle, tmp_path):
     want, _, _, _ = oracle.tvcsad_global(a, b, np.zeros((2, h, w), np.float32), warps=2)
     got = F.flo.read_flo(str(tmp_path / "out.flo"))
     assert bits_equal(got, want), mismatch_report(got, want)
+
+
+def test_match_growing_weighted_functional(ctx, oracle):
+    # -m 1 (M_TVL1_W): per-pixel Gaussian weights on the data term, lambda rescaled by the (sic) off-centre weight
+    i0, i1 = sintel_pair((640, 100, 72, 52))
+    a, b = oracle.preprocess_local(i0, i1)
+    go, ba = _seed_flows(oracle, a, b, 0.02, seed=31)
+    want, wene, st = oracle.local_faldoi(a, b, go, ba, method=1)
+    got, gene, gst = ctx.match_growing(a, b, go, ba, preprocessed=1, method=1)
+    assert list(gst.solves) == [st[1], st[4]] and list(gst.pops) == [st[0], st[3]]
+    assert bits_equal(got, want), mismatch_report(got, want)
+    assert bits_equal(gene, wene)
+    plain, _, _ = oracle.local_faldoi(a, b, go, ba, method=0)
+    assert not bits_equal(plain, want)                       # the weights do change the result
