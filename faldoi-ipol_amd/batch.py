@@ -3,8 +3,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         faldoi-ipol_amd/batch.py jobs.txt [-w 5] [-max_inner 400] [-tol_stop 1]
 
-jobs.txt: one job per line, `I0.png I1.png in_flow.flo|zero out.flo` (what one `global_faldoi` call
-takes, 2-line list-file semantics).  All pairs must have one size.
+jobs.txt: one job per line, all of one form and one image size:
+  `I0.png I1.png in_flow.flo|zero out.flo`   what one `global_faldoi` call takes (2-line list-file semantics);
+  `I0.png I1.png s0.flo s1.flo out.flo`      the whole chain of the driver scripts from the sparse seed flows:
+                                             `local_faldoi` (-m 0, all the growings of a shard in one batch) then
+                                             `global_faldoi` on its result.
 
 Data path: rank 0 decodes the inputs and SCATTERS them over RCCL
 (uint8 frames + fp32 initial flows, one message per rank), every rank prepares and solves its
@@ -27,9 +30,11 @@ def parse_jobs(path):
             parts = line.split()
             if not parts or parts[0].startswith("#"):
                 continue
-            if len(parts) != 4:
-                raise ValueError("%s:%d: expected `I0 I1 in_flow|zero out.flo`" % (path, ln))
+            if len(parts) not in (4, 5):
+                raise ValueError("%s:%d: expected `I0 I1 in_flow|zero out.flo` or `I0 I1 s0.flo s1.flo out.flo`" % (path, ln))
             jobs.append(tuple(parts))
+    if len({len(j) for j in jobs}) > 1:
+        raise ValueError("%s: global-only and pipeline jobs cannot be mixed" % path)
     return jobs
 
 
@@ -39,13 +44,15 @@ def shard_sizes(njobs, world):
 
 
 def scatter_inputs(dist, torch, device, rank, world, frames, flows, shape):
-    """frames: (njobs, 2, 3, h, w) uint8 on rank 0 (None elsewhere); flows: (njobs, 2, h, w) float32.
+    """frames: (njobs, 2, 3, h, w) uint8 on rank 0 (None elsewhere); flows: (njobs, 2, h, w) float32
+    (initial flows) or (njobs, 4, h, w) (forward and backward seed flows).  shape: (njobs, h, w[, planes]).
     Returns this rank's (frames_shard, flows_shard) as numpy arrays."""
-    njobs, h, w = shape
+    planes = shape[3] if len(shape) > 3 else 2
+    njobs, h, w = shape[:3]
     idx = shard_sizes(njobs, world)
     cap = max(len(i) for i in idx)                       # equal-size messages: pad the short shards
     my_fr = torch.empty((cap, 2, 3, h, w), dtype=torch.uint8, device=device)
-    my_fl = torch.empty((cap, 2, h, w), dtype=torch.float32, device=device)
+    my_fl = torch.empty((cap, planes, h, w), dtype=torch.float32, device=device)
     if rank == 0:
         fr_list, fl_list = [], []
         for r in range(world):
@@ -63,7 +70,7 @@ def scatter_inputs(dist, torch, device, rank, world, frames, flows, shape):
 
 def gather_flows(dist, torch, device, rank, world, flows_mine, shape):
     """Inverse of scatter_inputs for the results: returns (njobs, 2, h, w) on rank 0, None elsewhere."""
-    njobs, h, w = shape
+    njobs, h, w = shape[:3]
     idx = shard_sizes(njobs, world)
     cap = max(len(i) for i in idx)
     buf = torch.zeros((cap, 2, h, w), dtype=torch.float32, device=device)
@@ -88,6 +95,11 @@ def solve_shard_gpu(frames, flows, local_rank, **params):
         return np.empty((0,) + flows.shape[1:], np.float32), []
     h, w = frames.shape[-2:]
     ctx = F.Context(local_rank)
+    if flows.shape[1] == 4:                 # pipeline jobs: the local step first, every growing of the shard at once
+        i0s = [frames[i, 0].astype(np.float32) for i in range(n)]
+        i1s = [frames[i, 1].astype(np.float32) for i in range(n)]
+        local, _, _ = ctx.match_growing_batch(i0s, i1s, [flows[i, :2] for i in range(n)], [flows[i, 2:] for i in range(n)])
+        flows = np.stack(local)
     b = F.Tvl1Batch(ctx, n, w, h)
     for i in range(n):
         b.upload_images(i, frames[i, 0].astype(np.float32), frames[i, 1].astype(np.float32), flows[i])
@@ -133,12 +145,15 @@ def main(argv=None):
         fr = [[np.asarray(Image.open(p).convert("RGB")).transpose(2, 0, 1) for p in job[:2]] for job in jobs]
         frames = np.ascontiguousarray(np.array(fr, dtype=np.uint8))
         h, w = frames.shape[-2:]
-        flows = np.stack([np.zeros((2, h, w), np.float32) if job[2] == "zero" else F.flo.read_flo(job[2])
-                          for job in jobs])
-        meta = [(len(jobs), h, w, [job[3] for job in jobs])]
+        if len(jobs[0]) == 5:
+            flows = np.stack([np.concatenate([F.flo.read_flo(job[2]), F.flo.read_flo(job[3])]) for job in jobs])
+        else:
+            flows = np.stack([np.zeros((2, h, w), np.float32) if job[2] == "zero" else F.flo.read_flo(job[2])
+                              for job in jobs])
+        meta = [(len(jobs), h, w, [job[-1] for job in jobs], flows.shape[1])]
     dist.broadcast_object_list(meta, src=0)                     # the job table
-    njobs, h, w, outs = meta[0]
-    my_fr, my_fl = scatter_inputs(dist, torch, device, rank, world, frames, flows, (njobs, h, w))
+    njobs, h, w, outs, planes = meta[0]
+    my_fr, my_fl = scatter_inputs(dist, torch, device, rank, world, frames, flows, (njobs, h, w, planes))
     res, iters = solve_shard_gpu(my_fr, my_fl, local_rank, **params)
     allres = gather_flows(dist, torch, device, rank, world, res, (njobs, h, w))
     if rank == 0:

@@ -697,3 +697,33 @@ def test_match_growing_weighted_functional(ctx, oracle):
     assert bits_equal(gene, wene)
     plain, _, _ = oracle.local_faldoi(a, b, go, ba, method=0)
     assert not bits_equal(plain, want)                       # the weights do change the result
+
+
+def test_batch_driver_pipeline_jobs_over_rccl(oracle, tmp_path):
+    # batch.py with pipeline jobs (seed flows -> local step -> global step) under torch.distributed.run / RCCL
+    import sys
+    from PIL import Image
+    crops = [(400, 150, 64, 48), (100, 40, 64, 48)]
+    lines, want = [], []
+    for i, c in enumerate(crops):
+        i0, i1 = sintel_pair(c)
+        for k, im in enumerate((i0, i1)):
+            Image.fromarray(im.transpose(1, 2, 0).astype(np.uint8), "RGB").save(tmp_path / ("p%d_%d.png" % (i, k)))
+        a, b = oracle.preprocess_local(i0, i1)
+        go, ba = _seed_flows(oracle, a, b, 0.02, seed=50 + i)
+        F.flo.write_flo(str(tmp_path / ("s%d_0.flo" % i)), go)
+        F.flo.write_flo(str(tmp_path / ("s%d_1.flo" % i)), ba)
+        lines.append("%s %s %s %s %s" % (tmp_path / ("p%d_0.png" % i), tmp_path / ("p%d_1.png" % i), tmp_path / ("s%d_0.flo" % i),
+                                         tmp_path / ("s%d_1.flo" % i), tmp_path / ("o%d.flo" % i)))
+        local, _, _ = oracle.local_faldoi(a, b, go, ba)
+        g0, g1 = oracle.preprocess_global(i0, i1)
+        want.append(oracle.tvl1_global(g0, g1, local, warps=2, max_inner=40)[0])
+    (tmp_path / "jobs.txt").write_text("\n".join(lines) + "\n")
+    root = GOLDEN.rsplit("/tests/", 1)[0]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29543", root + "/faldoi-ipol_amd/batch.py",
+                        str(tmp_path / "jobs.txt"), "-w", "2", "-max_inner", "40"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i in range(len(crops)):
+        got = F.flo.read_flo(str(tmp_path / ("o%d.flo" % i)))
+        assert bits_equal(got, want[i]), i

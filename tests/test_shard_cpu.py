@@ -59,6 +59,13 @@ def _batch_worker(rank, world, port, q):
     frames = rng.integers(0, 256, (njobs, 2, 3, h, w), dtype=np.uint8) if rank == 0 else None
     flows = rng.standard_normal((njobs, 2, h, w)).astype(np.float32) if rank == 0 else None
     dev = torch.device("cpu")
+    # pipeline jobs carry four planes per pair (forward and backward seed flows)
+    seeds = rng.standard_normal((njobs, 4, h, w)).astype(np.float32) if rank == 0 else None
+    _, sd = F2.batch.scatter_inputs(dist, torch, dev, rank, world, frames, seeds, (njobs, h, w, 4))
+    assert sd.shape == (len(F2.batch.shard_sizes(njobs, world)[rank]), 4, h, w)
+    back = F2.batch.gather_flows(dist, torch, dev, rank, world, sd[:, 2:], (njobs, h, w))
+    if rank == 0:
+        assert np.array_equal(back, seeds[:, 2:])
     fr, fl = F2.batch.scatter_inputs(dist, torch, dev, rank, world, frames, flows, (njobs, h, w))
     # stand-in for the GPU solve (not available in CI): a deterministic function of the inputs
     res = fl + fr[:, 0, 0].astype(np.float32).mean(axis=(1, 2))[:, None, None, None]
@@ -91,6 +98,11 @@ def test_batch_job_file_parsing(tmp_path):
     f.write_text("# comment\na.png b.png zero o1.flo\n\nc.png d.png in.flo o2.flo\n")
     assert F.batch.parse_jobs(str(f)) == [("a.png", "b.png", "zero", "o1.flo"), ("c.png", "d.png", "in.flo", "o2.flo")]
     f.write_text("a.png b.png\n")
+    with pytest.raises(ValueError):
+        F.batch.parse_jobs(str(f))
+    f.write_text("a.png b.png s0.flo s1.flo o.flo\n")
+    assert F.batch.parse_jobs(str(f)) == [("a.png", "b.png", "s0.flo", "s1.flo", "o.flo")]
+    f.write_text("a.png b.png s0.flo s1.flo o.flo\nc.png d.png zero o2.flo\n")
     with pytest.raises(ValueError):
         F.batch.parse_jobs(str(f))
     assert F.batch.shard_sizes(5, 2) == [[0, 2, 4], [1, 3]]
