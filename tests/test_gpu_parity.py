@@ -727,3 +727,33 @@ def test_batch_driver_pipeline_jobs_over_rccl(oracle, tmp_path):
     for i in range(len(crops)):
         got = F.flo.read_flo(str(tmp_path / ("o%d.flo" % i)))
         assert bits_equal(got, want[i]), i
+
+
+def test_match_growing_edge_cases(ctx, oracle):
+    # tiny frame, dense seeds (every pixel a seed: the queue's worst case), small radii, one seed only
+    i0n, i1n, gt = synthetic_pair(40, 28, seed=5, amp=1.5)
+    rng = np.random.default_rng(12)
+    dense = np.round(gt + rng.standard_normal(gt.shape) * 0.4).astype(np.float32)
+    want, wene, st = oracle.local_faldoi(i0n, i1n, dense, -dense, loc_it=2)
+    got, gene, gst = ctx.match_growing(i0n, i1n, dense, -dense, preprocessed=1, loc_it=2, budget=500)
+    assert bits_equal(got, want) and bits_equal(gene, wene) and list(gst.pops) == [st[0], st[3]]
+    for wr in (1, 2):
+        sparse = np.full_like(dense, np.nan)
+        sparse[:, ::7, ::9] = dense[:, ::7, ::9]
+        want, wene, st = oracle.local_faldoi(i0n, i1n, sparse, -sparse, wr=wr, loc_it=1)
+        got, gene, gst = ctx.match_growing(i0n, i1n, sparse, -sparse, preprocessed=1, wr=wr, loc_it=1)
+        assert bits_equal(got, want), wr
+    one = np.full_like(dense, np.nan)
+    one[:, 14, 20] = (1.0, -1.0)
+    want, wene, st = oracle.local_faldoi(i0n, i1n, one, one)
+    got, gene, gst = ctx.match_growing(i0n, i1n, one, one, preprocessed=1)
+    assert bits_equal(got, want) and bits_equal(gene, wene)
+    t0, t1, tg = synthetic_pair(9, 7, seed=6, amp=0.5)                      # windows clipped on every side
+    s = np.full_like(tg, np.nan)
+    s[:, 3, 4] = 0.0
+    s[:, 0, 0] = (1.0, 0.0)
+    want, wene, st = oracle.local_faldoi(t0, t1, s, s)
+    got, gene, gst = ctx.match_growing(t0, t1, s, s, preprocessed=1)
+    assert bits_equal(got, want) and bits_equal(gene, wene)
+    with pytest.raises(F.FaldoiError):
+        ctx.match_growing(t0, t1, s, s, preprocessed=1, wr=6)               # window larger than the kernel's 11x11
