@@ -549,10 +549,9 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
 }
 
 // mode 0: the seed pass of insert_initial_seeds (:764-783); mode 1: local_growing (:899-937).
-__global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__restrict__ dirs, size_t pe, int nx, int ny,
-                                                           int mode, int iteration, int wr, int max_iter_patch, int budget)
+__device__ __forceinline__ void grow_body(GrowShared &sm, const GrowDir *__restrict__ dirs, size_t pe, int nx, int ny, int mode,
+                                          int iteration, int wr, int max_iter_patch, int budget)
 {
-    __shared__ GrowShared sm;
     const GrowDir D = dirs[blockIdx.x];
     const int t = threadIdx.x;
     int heap_size = 0, seed_pos = 0;
@@ -623,6 +622,26 @@ __global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__re
         D.ctl->cyc_fill += cyc[1];
         D.ctl->cyc_solve += cyc[2];
     }
+}
+
+// Two builds of the same body.  A growing is latency-bound (one instruction per ~5 cycles per wavefront), so a CU
+// gains from more resident growings as long as they fit: the default build uses ~190 VGPRs (2 wavefronts per SIMD,
+// 4 growings per CU); the dense build is held to 128 VGPRs (a few spills, ~8 % slower per growing) and fits 8 per
+// CU.  Measured on 256x192 pairs: 512 pairs 26.7 M windows/s with the default build, 1024 pairs 28.6 M (default)
+// vs 35.7 M (dense).  The host picks by the number of growings.
+__global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__restrict__ dirs, size_t pe, int nx, int ny,
+                                                           int mode, int iteration, int wr, int max_iter_patch, int budget)
+{
+    __shared__ GrowShared sm;
+    grow_body(sm, dirs, pe, nx, ny, mode, iteration, wr, max_iter_patch, budget);
+}
+
+__global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void grow_kernel_dense(const GrowDir *__restrict__ dirs, size_t pe, int nx, int ny, int mode, int iteration, int wr,
+                       int max_iter_patch, int budget)
+{
+    __shared__ GrowShared sm;
+    grow_body(sm, dirs, pe, nx, ny, mode, iteration, wr, max_iter_patch, budget);
 }
 
 // Reset of insert_initial_seeds :755-761 / insert_potential_candidates :839-845 / prepare_data_for_growing.

@@ -519,6 +519,14 @@ def test_match_growing_bit_exact(ctx, oracle, crop, frac):
     assert bits_equal(got, want), mismatch_report(got, want)
     assert bits_equal(got_ene, want_ene)
     assert np.isfinite(got).all()
+    if crop[0] == 400:                      # the register-capped build used for very large batches: same bits
+        import os
+        os.environ["FALDOI_GROW_DENSE"] = "1"
+        try:
+            got2, ene2, _ = ctx.match_growing(i0, i1, go, ba)
+        finally:
+            os.environ.pop("FALDOI_GROW_DENSE")
+        assert bits_equal(got2, want) and bits_equal(ene2, want_ene)
 
 
 def test_three_cli_pipeline_matches_cpu_path(ctx, oracle, tmp_path):
