@@ -67,14 +67,15 @@ def _build_lock():
 
 
 def build(force=False, verbose=False):
+    extra = os.environ.get("FALDOI_EXTRA_FLAGS", "").split()      # development aid (bisecting kernels)
     if not force and not needs_build():
         return SO
     with _build_lock():
         if not force and not needs_build():          # another process built it while we waited
             return SO
         tmp = SO + ".tmp.%d" % os.getpid()
-        cmd = [hipcc()] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
-                                        "-o", tmp] + SOURCES
+        cmd = [hipcc()] + HIPCC_FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+                                                "-o", tmp] + SOURCES
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -33,6 +33,7 @@ EXPORTS = [
     "faldoi_local_default_params", "faldoi_preprocess_local", "faldoi_match_growing_variational",
     "faldoi_match_growing_batch", "faldoi_queue_replay",
     "faldoi_fb_consistency_check", "faldoi_tvcsad_default_params", "faldoi_tvcsad_global",
+    "faldoi_queue_replay_device",
 ]
 
 
@@ -143,6 +144,7 @@ def lib():
                                                    C.POINTER(LocalParams), _F, _F, C.POINTER(LocalStats)]
     _I32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
     L.faldoi_queue_replay.argtypes = [C.c_int, _I32, _F, _I32, C.POINTER(C.c_int)]
+    L.faldoi_queue_replay_device.argtypes = [vp, C.c_int, _I32, _F, _I32, C.POINTER(C.c_int)]
     L.faldoi_fb_consistency_check.argtypes = [vp, _F, _F, C.c_int, C.c_int, C.c_float, _I32, C.POINTER(C.c_int)]
     L.faldoi_tvcsad_default_params.argtypes = [C.POINTER(Tvl1Params)]
     L.faldoi_tvcsad_default_params.restype = None
@@ -264,6 +266,15 @@ class Context:
         st.err = errs.ctypes.data_as(C.POINTER(C.c_float))
         _check(lib().faldoi_tvcsad_global(self._h, i0n, i1n, u, xi.ctypes.data_as(C.c_void_p), w, h, C.byref(p), C.byref(st)))
         return u, its, errs, xi, st
+
+    def queue_replay(self, ops, sims):
+        """queue_replay on the device queue (one wavefront).  Returns the popped ids."""
+        ops = np.ascontiguousarray(ops, np.int32)
+        sims = _f32(sims)
+        out = np.empty(len(ops), np.int32)
+        n = C.c_int(0)
+        _check(lib().faldoi_queue_replay_device(self._h, len(ops), ops, sims, out, C.byref(n)))
+        return out[:n.value]
 
     def fb_consistency_check(self, in0, in1, epsilon=2.0):
         """Mirror of fb_consistency_check: (2,h,w) forward / backward flows -> trust (h,w) int32."""

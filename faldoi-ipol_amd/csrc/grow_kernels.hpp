@@ -386,97 +386,92 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
 
 // ---------------------------------------------------------------------------------------------
 // The candidate queue on the device: the element moves of grow_heap.hpp (the definition, shared with
-// the host), arranged so that one lane has several levels of the tree in flight at once -- a heap
-// walk is a chain of dependent HBM/L2 round trips otherwise.
-//   pop : the children, grandchildren and great-grandchildren of the hole are 2 + 4 + 8 CONSECUTIVE
-//         elements; they are loaded together and three levels are resolved per round trip.
-//   push: the ancestors of the new slot are known from its index alone; eight are loaded at once.
+// the host), carried out by the 64 lanes of the FIRST wavefront together.  A heap walk by one lane is a
+// chain of dependent round trips and, above all, ~1000 instructions of a wavefront that issues one
+// instruction per ~5 cycles; with the lanes side by side:
+//   pop : the 62 descendants of the hole down to depth 5 are loaded by lanes 0..61 in ONE instruction
+//         (lane L holds the node at depth d = floor(log2(L+2)), offset L+2-2^d); the walk compares two
+//         `readlane`d energies per level, marks the lane of the winning child, and the marked lanes store
+//         their element into their parent's slot -- five levels per round trip;
+//   push: lane q loads the q-th ancestor of the new slot; a ballot of `ancestor.sim > value.sim` gives the
+//         number m of leading ancestors that move down (count of trailing ones); lanes 0..m-1 store one
+//         slot lower, lane 0 drops the value into ancestor m-1's slot.
+// Every function below is called by all lanes of wavefront 0 with identical arguments.
+// Elements travel as native 4-vectors {sim, u, v, bits(ij)} (selecting between structs, or HIP's
+// union-based float4, goes through memory).
 // ---------------------------------------------------------------------------------------------
-// Elements travel as native 4-vectors {sim, u, v, bits(ij)} with component-wise selection (selecting
-// between structs, or HIP's union-based cand4, goes through memory).
 typedef float cand4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) cand4 *heap_ptr;      // the queue lives in global memory: plain global loads, not flat ones
-__device__ __forceinline__ cand4 sel4(bool c, const cand4 a, const cand4 b)
+typedef __attribute__((address_space(1))) cand4 *heap_ptr;      // the queue lives in global memory: plain global loads
+
+__device__ __forceinline__ float lane_read(float v, int lane)    // lane: wave-uniform
 {
-    cand4 r;
-    r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; r.z = c ? a.z : b.z; r.w = c ? a.w : b.w;
-    return r;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-__device__ __forceinline__ void heap_sift_up_dev(heap_ptr h, int hole, const cand4 value)
+__device__ __forceinline__ void heap_sift_up_wave(heap_ptr h, int hole, const cand4 value)
 {
+    const int lane = threadIdx.x & 63;
     while (hole > 0) {
-        const int i0 = ((hole + 1) >> 1) - 1, i1 = ((hole + 1) >> 2) - 1, i2 = ((hole + 1) >> 3) - 1, i3 = ((hole + 1) >> 4) - 1;
-        const int i4 = ((hole + 1) >> 5) - 1, i5 = ((hole + 1) >> 6) - 1, i6 = ((hole + 1) >> 7) - 1, i7 = ((hole + 1) >> 8) - 1;
-        const cand4 a0 = h[i0 < 0 ? 0 : i0], a1 = h[i1 < 0 ? 0 : i1], a2 = h[i2 < 0 ? 0 : i2], a3 = h[i3 < 0 ? 0 : i3];
-        const cand4 a4 = h[i4 < 0 ? 0 : i4], a5 = h[i5 < 0 ? 0 : i5], a6 = h[i6 < 0 ? 0 : i6], a7 = h[i7 < 0 ? 0 : i7];
-        bool placed = false;
-#define FALDOI_SIFT_STEP(IDX, ANC)                                                      \
-        if (!placed) {                                                                  \
-            if ((IDX) < 0 || !((ANC).x > value.x)) placed = true;                       \
-            else { h[hole] = (ANC); hole = (IDX); }                                     \
-        }
-        FALDOI_SIFT_STEP(i0, a0) FALDOI_SIFT_STEP(i1, a1) FALDOI_SIFT_STEP(i2, a2) FALDOI_SIFT_STEP(i3, a3)
-        FALDOI_SIFT_STEP(i4, a4) FALDOI_SIFT_STEP(i5, a5) FALDOI_SIFT_STEP(i6, a6) FALDOI_SIFT_STEP(i7, a7)
-#undef FALDOI_SIFT_STEP
-        if (placed) break;
+        const bool have = lane < 24 && ((hole + 1) >> (lane + 1)) > 0;        // lane q <-> q-th ancestor
+        const int aidx = have ? ((hole + 1) >> (lane + 1)) - 1 : 0;
+        const cand4 mine = h[aidx];
+        const unsigned long long down = __builtin_amdgcn_ballot_w64(have && mine.x > value.x);
+        const int m = __builtin_ctzll(~down);                                 // leading ancestors that move down
+        if (lane < m) h[((hole + 1) >> lane) - 1] = mine;                     // into the slot of ancestor lane-1 (the hole for lane 0)
+        if (m == 0) break;
+        hole = ((hole + 1) >> m) - 1;
+        if (m < 24) break;
     }
-    h[hole] = value;
+    if (lane == 0) h[hole] = value;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // later loads by OTHER lanes must see these stores
 }
 
-__device__ __forceinline__ void heap_push_dev(Candidate *heap, int &size, const Candidate &value)
+__device__ __forceinline__ void heap_push_wave(Candidate *heap, int &size, int px, int py, float u, float v, float sim)
 {
-    heap_sift_up_dev((heap_ptr)(heap), size,
-                     cand4{ value.sim, value.u, value.v, __uint_as_float(value.ij) });
+    heap_sift_up_wave((heap_ptr)(heap), size, cand4{ sim, u, v, __uint_as_float((unsigned)px | ((unsigned)py << 16)) });
     ++size;
 }
 
 // Removes the top (the caller has read element 0); precondition: size > 0.
-__device__ __forceinline__ void heap_remove_top_dev(Candidate *heap, int &size)
+__device__ __forceinline__ void heap_remove_top_wave(Candidate *heap, int &size)
 {
     heap_ptr h = (heap_ptr)(heap);
+    const int lane = threadIdx.x & 63;
     const int len = --size;
     if (len == 0) return;
     const cand4 value = h[len];
     const int half = (len - 1) / 2;                                 // nodes below `half` have two children
     const int last = len - 1;
+    const int d = 31 - __builtin_clz(lane + 2);                     // depth of this lane's node under the hole, 1..5 (6: unused)
+    const int off = lane + 2 - (1 << d);
     int hole = 0;
     while (hole < half) {
-        const int r1 = 2 * (hole + 1);                              // right child; children = [r1-1, r1],
-        const int e2 = 2 * r1 - 1, e3 = 4 * r1 - 1;                 // grandchildren = [2r1-1, 2r1+2], next = [4r1-1, 4r1+6]
-        const cand4 p0 = h[r1 - 1], p1 = h[r1];
-        const cand4 q0 = h[e2 < last ? e2 : last], q1 = h[e2 + 1 < last ? e2 + 1 : last], q2 = h[e2 + 2 < last ? e2 + 2 : last],
-                     q3 = h[e2 + 3 < last ? e2 + 3 : last];
-        const cand4 s0 = h[e3 < last ? e3 : last], s1 = h[e3 + 1 < last ? e3 + 1 : last], s2 = h[e3 + 2 < last ? e3 + 2 : last],
-                     s3 = h[e3 + 3 < last ? e3 + 3 : last], s4 = h[e3 + 4 < last ? e3 + 4 : last],
-                     s5 = h[e3 + 5 < last ? e3 + 5 : last], s6 = h[e3 + 6 < last ? e3 + 6 : last],
-                     s7 = h[e3 + 7 < last ? e3 + 7 : last];
-        // level 1
-        const bool right1 = !(p1.x > p0.x);                         // comp(right, left) picks the left child
-        h[hole] = sel4(right1, p1, p0);
-        hole = right1 ? r1 : r1 - 1;
-        if (!(hole < half)) break;
-        // level 2: the pair of the chosen child
-        const cand4 a0 = sel4(right1, q2, q0), a1 = sel4(right1, q3, q1);
-        const bool right2 = !(a1.x > a0.x);
-        h[hole] = sel4(right2, a1, a0);
-        const int r2 = 2 * (hole + 1);
-        hole = right2 ? r2 : r2 - 1;
-        if (!(hole < half)) break;
-        // level 3
-        const cand4 b0 = sel4(right1, sel4(right2, s6, s4), sel4(right2, s2, s0));
-        const cand4 b1 = sel4(right1, sel4(right2, s7, s5), sel4(right2, s3, s1));
-        const bool right3 = !(b1.x > b0.x);
-        h[hole] = sel4(right3, b1, b0);
-        const int r3 = 2 * (hole + 1);
-        hole = right3 ? r3 : r3 - 1;
+        const int idx = ((hole + 1) << d) - 1 + off;
+        const cand4 mine = h[(d <= 5 && idx <= last) ? idx : last];
+        bool onpath = false;
+        int cur = hole, rel = 0;                                    // rel: position of `cur` within its level of the subtree
+#pragma unroll
+        for (int dd = 1; dd <= 5; ++dd) {
+            if (cur < half) {                                       // both children exist
+                const int left = (1 << dd) - 2 + 2 * rel;           // lane that holds the left child
+                const float sl = lane_read(mine.x, left), sr = lane_read(mine.x, left + 1);
+                const int right = (sr > sl) ? 0 : 1;                // comp(right, left) picks the left child
+                onpath = onpath || lane == left + right;
+                cur = 2 * cur + 1 + right;
+                rel = 2 * rel + right;
+            }
+        }
+        if (onpath) h[(idx - 1) >> 1] = mine;                       // every element of the path moves into its parent's slot
+        hole = cur;
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if ((len & 1) == 0 && hole == (len - 2) / 2) {                  // the one node with a single (left) child
         const int child = 2 * (hole + 1);
-        h[hole] = h[child - 1];
+        const cand4 c = h[child - 1];
+        if (lane == 0) h[hole] = c;
         hole = child - 1;
     }
-    heap_sift_up_dev(h, hole, value);
+    heap_sift_up_wave(h, hole, value);
 }
 
 // add_neighbors (src/local_faldoi.cpp:679-727) for the pixel (i, j), all 128 threads.
@@ -492,12 +487,12 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
     const int p = (ij + (act ? t / pw : 0)) * nx + ii + (act ? t % pw : 0);
     bool fill = iteration == 0;
     if (!fill) fill = __syncthreads_or(act && D.trust[p] == 0);                   // check_trustable_patch :639-656
-    // thread 0: state of the four neighbours and of the centre, read now so that the latency hides behind the
-    // window computation (only thread 0 ever writes these arrays during a growing)
+    // first wavefront (uniformly): state of the four neighbours and of the centre, read now so that the latency
+    // hides behind the window computation (only lane 0 ever writes these arrays during a growing)
     const int nbx[4] = { 0, 0, 1, -1 }, nby[4] = { 1, -1, 0, 0 };                 // insert_candidates :501-505
     int nfix[4] = { 1, 1, 1, 1 };
     float nene[4] = { 0, 0, 0, 0 }, nsal[4] = { 1.0f, 1.0f, 1.0f, 1.0f }, cene = 0.0f;
-    if (t == 0) {
+    if (t < 64) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int px = i + nbx[q], py = j + nby[q];
@@ -523,24 +518,27 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
     const int iiw = (i - wr < 0) ? -(i - wr) : 0, ijw = (j - wr < 0) ? -(j - wr) : 0;    // get_relative_index_weight :551-557
     const float ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2, D.weight, iiw, ijw, wr);
     const long long c2 = clock64();
-    if (t == 0) {                                                                 // insert_candidates :497-537
+    if (t < 64) {                                                                 // insert_candidates :497-537
+        const float ener0 = lane_read(ener, 0);                                   // lane 0 summed the energy
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int px = i + nbx[q], py = j + nby[q];
-            const float new_ener = ener * nsal[q];
-            if (!nfix[q] && new_ener < nene[q]) {                                 // outside the image: nfix = 1
-                D.ene[py * nx + px] = ener;
+            const float new_ener = ener0 * nsal[q];
+            if (!nfix[q] && new_ener < nene[q]) {                                 // outside the image: nfix = 1 (wave-uniform test)
+                if (t == 0) D.ene[py * nx + px] = ener0;
                 const int wq = (py - ij) * pw + (px - ii);                        // the neighbour lies in the window
-                if (heap_size < D.heap_cap) heap_push_dev(D.heap, heap_size, make_candidate(px, py, sm.a[wq], sm.b[wq], new_ener));
-                else D.ctl->pad = 1;
+                if (heap_size < D.heap_cap) heap_push_wave(D.heap, heap_size, px, py, sm.a[wq], sm.b[wq], new_ener);
+                else if (t == 0) D.ctl->pad = 1;
             }
         }
         const int g = j * nx + i, wq = (j - ij) * pw + (i - ii);                  // :718-726
-        if (cene > ener) {
+        if (t == 0 && cene > ener0) {
             D.out[g] = sm.a[wq];
             D.out[pe + g] = sm.b[wq];
-            D.ene[g] = ener;
+            D.ene[g] = ener0;
         }
+    }
+    if (t == 0) {
         cyc[0] += clock64() - c2;
         cyc[1] += c1 - c0;
         cyc[2] += c2 - c1;
@@ -557,44 +555,51 @@ __device__ __forceinline__ void grow_body(GrowShared &sm, const GrowDir *__restr
     int heap_size = 0, seed_pos = 0;
     long long pops = 0, solves = 0, fills = 0;
     long long cyc[3] = { 0, 0, 0 };
-    if (t == 0) {
+    if (t < 64) {                                   // the first wavefront runs the queue; its lanes hold the same counters
         heap_size = D.ctl->heap_size;
         seed_pos = D.ctl->seed_pos;
     }
     int done = 0;
     for (int step = 0; step < budget; ++step) {
-        if (t == 0) {
+        if (t < 64) {
             int have = 0, g = 0;
             const long long c0 = clock64();
             if (mode == 0) {
                 if (seed_pos < D.nseeds) {
                     g = D.seeds[seed_pos++];
-                    D.out[g] = D.seed_flow[g];
-                    D.out[pe + g] = D.seed_flow[pe + g];
-                    D.fixed[g] = 1;
+                    if (t == 0) {
+                        D.out[g] = D.seed_flow[g];
+                        D.out[pe + g] = D.seed_flow[pe + g];
+                        D.fixed[g] = 1;
+                    }
                     have = 1;
                 }
             } else {
                 while (heap_size > 0) {
-                    const Candidate c = D.heap[0];
-                    const int ci = (int)(c.ij & 0xffffu), cj = (int)(c.ij >> 16);
+                    const cand4 c = ((heap_ptr)D.heap)[0];
+                    const unsigned cij = __float_as_uint(c.w);
+                    const int ci = (int)(cij & 0xffffu), cj = (int)(cij >> 16);
                     g = cj * nx + ci;
                     const int was_fixed = D.fixed[g];                             // in flight during the sift-down
-                    heap_remove_top_dev(D.heap, heap_size);
+                    heap_remove_top_wave(D.heap, heap_size);
                     ++pops;
                     if (was_fixed) continue;
-                    D.fixed[g] = 1;                                               // :926-932
-                    D.out[g] = c.u;
-                    D.out[pe + g] = c.v;
-                    D.ene[g] = c.sim;
+                    if (t == 0) {
+                        D.fixed[g] = 1;                                           // :926-932
+                        D.out[g] = c.y;
+                        D.out[pe + g] = c.z;
+                        D.ene[g] = c.x;
+                    }
                     have = 1;
                     break;
                 }
             }
-            cyc[0] += clock64() - c0;
-            sm.cur[0] = have;
-            sm.cur[1] = g % nx;
-            sm.cur[2] = g / nx;
+            if (t == 0) {
+                cyc[0] += clock64() - c0;
+                sm.cur[0] = have;
+                sm.cur[1] = g % nx;
+                sm.cur[2] = g / nx;
+            }
         }
         __syncthreads();
         if (!sm.cur[0]) { done = 1; break; }
@@ -642,6 +647,33 @@ void grow_kernel_dense(const GrowDir *__restrict__ dirs, size_t pe, int nx, int 
 {
     __shared__ GrowShared sm;
     grow_body(sm, dirs, pe, nx, ny, mode, iteration, wr, max_iter_patch, budget);
+}
+
+// Test hook: replays push (1) / pop (0) operations on the device queue with one wavefront.
+__global__ __launch_bounds__(kPatchThreads) void heap_replay_kernel(Candidate *heap, int nops, const int *__restrict__ ops,
+                                                                  const float *__restrict__ sims, int *__restrict__ popped,
+                                                                  int *__restrict__ npopped)
+{
+    // as in grow_body: two wavefronts, the first one runs the queue, its counters live in vector registers
+    if (threadIdx.x < 64) {
+        int size = npopped[0], np = npopped[0];              // both 0 (the compiler cannot know)
+        for (int k = 0; k < nops; ++k) {
+            if (ops[k]) {
+                heap_push_wave(heap, size, k & 0xffff, (k * 7) & 0x1ff, sims[k] * 3.0f + 1.0f, -sims[k], sims[k]);
+            } else if (size == 0) {
+                if (threadIdx.x == 0) popped[np] = -1;
+                ++np;
+            } else {
+                const cand4 c = ((heap_ptr)heap)[0];
+                heap_remove_top_wave(heap, size);
+                const unsigned cw = __float_as_uint(c.w);
+                const bool intact = c.y == c.x * 3.0f + 1.0f && c.z == -c.x && (cw >> 16) == (((cw & 0xffffu) * 7) & 0x1ff);
+                if (threadIdx.x == 0) popped[np] = intact ? (int)(cw & 0xffffu) : -2;     // payload travels with its key
+                ++np;
+            }
+        }
+        if (threadIdx.x == 0) *npopped = np;
+    }
 }
 
 // Reset of insert_initial_seeds :755-761 / insert_potential_candidates :839-845 / prepare_data_for_growing.

@@ -262,6 +262,7 @@ void faldoi_local_default_params(faldoi_local_params *p);
 /* Host-only replay of the candidate queue (pq_cand, src/energy_structures.h:13-30), for tests of the pop
  * order among equal energies: ops[k] = 1 pushes energy sims[k] with id k (k < 65536), 0 pops. */
 int faldoi_queue_replay(int nops, const int *ops, const float *sims, int *popped, int *npopped);
+int faldoi_queue_replay_device(faldoi_ctx *ctx, int nops, const int *ops, const float *sims, int *popped, int *npopped);
 /* prepare_stuff's image part for TV-l2 coupled (src/energy_model.cpp:660-684): gray, image_normalization
  * over the two frames (src/utils.cpp:703-734), Gaussian 0.9. */
 int faldoi_preprocess_local(faldoi_ctx *ctx, const float *i0, const float *i1, int nx, int ny, int pd, float *i0n,

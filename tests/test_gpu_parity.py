@@ -765,3 +765,15 @@ def test_match_growing_edge_cases(ctx, oracle):
     assert bits_equal(got, want) and bits_equal(gene, wene)
     with pytest.raises(F.FaldoiError):
         ctx.match_growing(t0, t1, s, s, preprocessed=1, wr=6)               # window larger than the kernel's 11x11
+
+
+def test_device_queue_pops_like_the_host_queue(ctx):
+    # the wavefront-wide heap walks against the shared host definition (itself tested against std::priority_queue)
+    rng = np.random.default_rng(6)
+    for levels, n, ppush in ((3, 300, 0.6), (16, 5000, 0.55), (100000, 30000, 0.7), (2, 65000, 0.62), (50, 4000, 0.5)):
+        ops = (rng.random(n) < ppush).astype(np.int32)
+        ops[:8] = 1
+        sims = rng.integers(0, levels, n).astype(np.float32) * 0.25
+        want = F.capi.queue_replay(ops, sims)
+        got = ctx.queue_replay(ops, sims)
+        assert np.array_equal(got, want), (levels, n, int(np.argmax(got != want)) if len(got) == len(want) else (len(got), len(want)))
