@@ -164,6 +164,11 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         // the column to the left (lane i-1 of the same 16-lane group); row_shr:1, zero at the row start
         const unsigned holes_left = (unsigned)__builtin_amdgcn_update_dpp(0, (int)holes, 0x111, 0xf, 0xf, true);
         wave_sync();
+        if (__builtin_amdgcn_ballot_w64(holes != 0u) == 0ull) {     // no hole at this level: the sweeps change nothing
+            for (int q = lane; q < w * h; q += 64) fin[o + q] = sm.ver[c][0][o + q];
+            wave_sync();
+            continue;
+        }
         const float *y0 = sm.ver[c][0] + o;                         // initial state: the value of every non-hole
         const float *yo = sm.ver[c][g < 3 ? g : 0] + o;             // state before this group's sweep
         float *yn = sm.ver[c][g < 3 ? g + 1 : 1] + o;               // state after it
