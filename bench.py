@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--growing-pairs", type=int, default=256)
+    ap.add_argument("--growing-pairs", type=int, default=512)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
