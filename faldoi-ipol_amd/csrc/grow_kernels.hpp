@@ -177,33 +177,39 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         // sweep was computed in the previous step: the upper neighbour by this lane (register), the left one by
         // lane i-1 (DPP).  Neighbours that are not holes keep their initial value in every version.
         int j = -3 * g - i;
-        float self, right, down, sleft, self_prev = 0.0f, nw = 0.0f, mx = 0.0f;
-        {
-            const int jc = j < 0 ? 0 : (j > h - 1 ? h - 1 : j);
-            const int idx = jc * w + ic;
-            self = yo[idx];
-            right = yo[idx + ((ic < w - 1) ? 1 : 0)];
-            down = yo[idx + ((jc < h - 1) ? w : 0)];
-            sleft = y0[idx - ((ic > 0) ? 1 : 0)];
-        }
+        // per-lane constants of the loop: element offsets of the right / lower / left neighbour, and running state:
+        // `base` = index of the row being prefetched (clamped into the level), hole bits shifted so that bit 0 is row j
+        const int roff = (ic < w - 1) ? 1 : 0, loff = (ic > 0) ? 1 : 0;
+        int base = ic;                                                // row clamp(j, 0, h-1) = 0 at the start (j <= 0)
+        unsigned hs = lane_on ? holes : 0u, hl = holes_left;
+        float self = yo[base], right = yo[base + roff], down = yo[base + ((h > 1) ? w : 0)], sleft = y0[base - loff];
+        float self_prev = 0.0f, nw = 0.0f, mx = 0.0f;
+        bool up_hole = false;
         const int steps = w + h - 1 + 6;
+#pragma unroll 2
         for (int st = 0; st < steps; ++st) {
             const float left_nw = __builtin_amdgcn_update_dpp(0.0f, nw, 0x111, 0xf, 0xf, true);
-            const int jn = j + 1, jc = jn < 0 ? 0 : (jn > h - 1 ? h - 1 : jn);
-            const int idxn = jc * w + ic;
-            const float self_n = yo[idxn], right_n = yo[idxn + ((ic < w - 1) ? 1 : 0)], down_n = yo[idxn + ((jc < h - 1) ? w : 0)];
-            const float sleft_n = y0[idxn - ((ic > 0) ? 1 : 0)];
-            if (lane_on && j >= 0 && j < h && ((holes >> j) & 1u)) {
+            const int cur = base;                                     // == j * w + i whenever row j is inside the level
+            const int jn = j + 1;
+            base += (jn >= 1 && jn <= h - 1) ? w : 0;                 // next row, clamped
+            const float self_n = yo[base], right_n = yo[base + roff], down_n = yo[base + ((jn < h - 1) ? w : 0)];
+            const float sleft_n = y0[base - loff];
+            const bool row_on = j >= 0;                               // rows >= h have no hole bit left
+            const bool self_hole = row_on && (hs & 1u);
+            if (self_hole) {
                 // getpixel_1 clamps to the pixel itself, not yet updated in this sweep
-                const float left = (i > 0) ? (((holes_left >> j) & 1u) ? left_nw : sleft) : self;
-                const float up = (j > 0) ? (((holes >> (j - 1)) & 1u) ? nw : self_prev) : self;
+                const float left = (i > 0) ? ((hl & 1u) ? left_nw : sleft) : self;
+                const float up = (j > 0) ? (up_hole ? nw : self_prev) : self;
                 const float lap = -4 * self + right + down + left + up;
                 const float res = self + 0.4f * lap;
                 const float update = __builtin_fabsf(self - res);
                 if (update > mx) mx = update;
-                yn[j * w + i] = res;
+                yn[cur] = res;
                 nw = res;
             }
+            up_hole = self_hole;
+            hs = row_on ? hs >> 1 : hs;
+            hl = row_on ? hl >> 1 : hl;
             self_prev = self;
             self = self_n; right = right_n; down = down_n; sleft = sleft_n;
             j = jn;
