@@ -21,6 +21,7 @@ namespace faldoi {
 
 constexpr int kNlR = 2, kNlSlots = 24;     // MAX_BETA / MAX_DUAL_VAR, src/global_faldoi.cpp:887-888
 constexpr int kCsR = 3, kCsSlots = 48;     // DT_R / DT_NEI, src/parameters.h:86-87
+constexpr int kCsBatch = 8;                // CSAD slots whose 2x8 neighbour loads are issued together (16: no faster, more registers)
 
 // Plane indices of one NLTV-CSAD problem
 enum NlPlane {
@@ -155,25 +156,35 @@ __device__ __forceinline__ void sort48(float (&v)[kCsSlots])
 // b_s = (I0[i] - I0[pos_s] - I1w[i] + I1w[pos_s] + t1 + t2) / sg recomputed from the 7x7 neighbourhoods.
 // A is sorted in registers (invalid slots = +inf); B is an arithmetic progression, so the order statistic
 // is  min over c of max(A_sorted[c-1], B_ascending[n+1-c])  -- the classic two-sorted-arrays split.
-__device__ __forceinline__ float csad_select(const float *__restrict__ I0, const float *__restrict__ I1w, int i, int x, int y,
+__device__ __forceinline__ float csad_select(const float *I0, const float *I1w, int i, int x, int y,
                                              int nx, int ny, float t1, float t2, float r, float sg, float l_t)
 {
     const float i0 = I0[i], i1w = I1w[i];
     const double rsg = recip_f64(sg);                       // sg >= 1e-4: 48 exact quotients share it
     float A[kCsSlots];
-    int n = 0, s = 0;
+    int n = 0;
+    // slot s <-> offset (k, l): rows -3..3, columns -3..3, centre skipped.  Eight slots at a time: their sixteen
+    // loads are issued together, then the eight quotients (the compiler otherwise waits for every pair of loads).
 #pragma unroll
-    for (int k = -kCsR; k <= kCsR; ++k)
+    for (int s0 = 0; s0 < kCsSlots; s0 += kCsBatch) {
+        float a0[kCsBatch], a1[kCsBatch];
+        bool ok[kCsBatch];
 #pragma unroll
-        for (int l = -kCsR; l <= kCsR; ++l) {
-            if (k == 0 && l == 0) continue;
-            const bool valid = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
-            const int pos = valid ? i + k * nx + l : i;
-            const float bs = div_by(i0 - I0[pos] - i1w + I1w[pos] + t1 + t2, sg, rsg);   // :1716-1717 / :1529-1530
-            A[s] = valid ? -(bs - r) : __builtin_inff();            // :1741-1742
-            n += valid ? 1 : 0;
-            ++s;
+        for (int q = 0; q < kCsBatch; ++q) {
+            const int s = s0 + q, c = s < 24 ? s : s + 1;           // position in the 7x7 raster (centre = 24)
+            const int k = c / 7 - kCsR, l = c % 7 - kCsR;
+            ok[q] = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
+            const int pos = ok[q] ? i + k * nx + l : i;
+            a0[q] = I0[pos];
+            a1[q] = I1w[pos];
         }
+#pragma unroll
+        for (int q = 0; q < kCsBatch; ++q) {
+            const float bs = div_by(i0 - a0[q] - i1w + a1[q] + t1 + t2, sg, rsg);       // :1716-1717 / :1529-1530
+            A[s0 + q] = ok[q] ? -(bs - r) : __builtin_inff();       // :1741-1742
+            n += ok[q] ? 1 : 0;
+        }
+    }
     sort48(A);
     float m = __builtin_inff();
 #pragma unroll
