@@ -21,6 +21,7 @@ namespace faldoi {
 
 constexpr int kNlR = 2, kNlSlots = 24;     // MAX_BETA / MAX_DUAL_VAR, src/global_faldoi.cpp:887-888
 constexpr int kCsR = 3, kCsSlots = 48;     // DT_R / DT_NEI, src/parameters.h:86-87
+constexpr int kNlBatch = 6;                // non-local slots whose 5x6 loads are issued together
 constexpr int kCsBatch = 8;                // CSAD slots whose 2x8 neighbour loads are issued together (16: no faster, more registers)
 
 // Plane indices of one NLTV-CSAD problem
@@ -77,25 +78,37 @@ __global__ __launch_bounds__(256) void nl_dual_kernel(float *__restrict__ base, 
     const float *ub1 = base + N_UB1 * pe, *ub2 = base + N_UB2 * pe;
     const float a1 = ub1[i], a2 = ub2[i], wt = base[N_WT * pe + i];
     const double rwt = recip_f64(wt);        // wt > 0 (every pixel has valid neighbours): shared by 48 quotients
-    int s = 0;
+    // Six slots at a time: their thirty loads are issued together (clamped address for slots outside the image);
+    // slots outside the image keep their duals (never written, as in the reference).
 #pragma unroll
-    for (int k = -kNlR; k <= kNlR; ++k)
+    for (int s0 = 0; s0 < kNlSlots; s0 += kNlBatch) {
+        float w_[kNlBatch], n1[kNlBatch], n2[kNlBatch], p0[kNlBatch], q0[kNlBatch];
+        bool ok[kNlBatch];
 #pragma unroll
-        for (int l = -kNlR; l <= kNlR; ++l) {
-            if (k == 0 && l == 0) continue;
-            if (x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny) {
-                const int ap = i + k * nx + l;
-                const float w = base[(size_t)(N_W + s) * pe + i];
-                float *pp = base + (size_t)(N_P + s) * pe + i, *qq = base + (size_t)(N_Q + s) * pe + i;
-                const float g1 = div_by(w * (a1 - ub1[ap]), wt, rwt);
-                const float d1 = 1 + tau * sqrt_of_square(g1);
-                *pp = (*pp + tau * g1) / d1;
-                const float g2 = div_by(w * (a2 - ub2[ap]), wt, rwt);
-                const float d2 = 1 + tau * sqrt_of_square(g2);
-                *qq = (*qq + tau * g2) / d2;
-            }
-            ++s;
+        for (int q = 0; q < kNlBatch; ++q) {
+            const int s = s0 + q, c = s < 12 ? s : s + 1;           // position in the 5x5 raster (centre = 12)
+            const int k = c / 5 - kNlR, l = c % 5 - kNlR;
+            ok[q] = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
+            const int ap = ok[q] ? i + k * nx + l : i;
+            w_[q] = base[(size_t)(N_W + s) * pe + i];
+            n1[q] = ub1[ap];
+            n2[q] = ub2[ap];
+            p0[q] = base[(size_t)(N_P + s) * pe + i];
+            q0[q] = base[(size_t)(N_Q + s) * pe + i];
         }
+#pragma unroll
+        for (int q = 0; q < kNlBatch; ++q) {
+            if (ok[q]) {
+                const int s = s0 + q;
+                const float g1 = div_by(w_[q] * (a1 - n1[q]), wt, rwt);
+                const float d1 = 1 + tau * sqrt_of_square(g1);
+                base[(size_t)(N_P + s) * pe + i] = (p0[q] + tau * g1) / d1;
+                const float g2 = div_by(w_[q] * (a2 - n2[q]), wt, rwt);
+                const float d2 = 1 + tau * sqrt_of_square(g2);
+                base[(size_t)(N_Q + s) * pe + i] = (q0[q] + tau * g2) / d2;
+            }
+        }
+    }
 }
 
 // Compare-exchange network for the 48 CSAD terms held in registers: Batcher's odd-even merge sort
@@ -226,21 +239,32 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
     }
     const float wt = base[N_WT * pe + i];
     float dp = 0.0f, dq = 0.0f;
-    int s = 0;
+    // non_local_divergence (:1056-1079): slot s <-> offset (k, l) in the 5x5 raster, centre skipped.  Six slots at a
+    // time: their thirty loads are issued together (clamped address for slots outside the image, result unused).
 #pragma unroll
-    for (int k = -kNlR; k <= kNlR; ++k)
+    for (int s0 = 0; s0 < kNlSlots; s0 += kNlBatch) {
+        float w_[kNlBatch], pa[kNlBatch], pb[kNlBatch], qa[kNlBatch], qb[kNlBatch];
+        bool ok[kNlBatch];
 #pragma unroll
-        for (int l = -kNlR; l <= kNlR; ++l) {
-            if (k == 0 && l == 0) continue;
-            if (x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny) {
-                const int ap = i + k * nx + l;
-                const int rp = kNlSlots - 1 - s;
-                const float w = base[(size_t)(N_W + s) * pe + i];
-                dp += w * (base[(size_t)(N_P + s) * pe + i] - base[(size_t)(N_P + rp) * pe + ap]);
-                dq += w * (base[(size_t)(N_Q + s) * pe + i] - base[(size_t)(N_Q + rp) * pe + ap]);
-            }
-            ++s;
+        for (int q = 0; q < kNlBatch; ++q) {
+            const int s = s0 + q, c = s < 12 ? s : s + 1;           // position in the 5x5 raster (centre = 12)
+            const int k = c / 5 - kNlR, l = c % 5 - kNlR;
+            ok[q] = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
+            const int ap = ok[q] ? i + k * nx + l : i;
+            const int rp = kNlSlots - 1 - s;
+            w_[q] = base[(size_t)(N_W + s) * pe + i];
+            pa[q] = base[(size_t)(N_P + s) * pe + i];
+            pb[q] = base[(size_t)(N_P + rp) * pe + ap];
+            qa[q] = base[(size_t)(N_Q + s) * pe + i];
+            qb[q] = base[(size_t)(N_Q + rp) * pe + ap];
         }
+#pragma unroll
+        for (int q = 0; q < kNlBatch; ++q) {
+            const float tp = dp + w_[q] * (pa[q] - pb[q]), tq = dq + w_[q] * (qa[q] - qb[q]);
+            dp = ok[q] ? tp : dp;
+            dq = ok[q] ? tq : dq;
+        }
+    }
     dp /= wt;
     dq /= wt;
     const float n1 = u1k - tau * (dp + (u1k - v1) / theta);              // :1106-1107, note +div
