@@ -189,15 +189,21 @@ __device__ __forceinline__ BicubicTaps bicubic_taps(float uu, float vv, int nx, 
 
 // :103-111 cubic_interpolation_cell.  (v2-v0) and (v1-v2) are fp32 subtractions; everything
 // that touches a double literal is fp64; one rounding to fp32 at the end.
+// The reference evaluates, without contraction,
+//     c3 = 3.0*d12 + v3 - v0;   c2 = 2.0*v0 - 5.0*v1 + 4.0*v2 - v3 + t*c3;   c1 = d20 + t*c2;   v1 + 0.5*t*c1.
+// A product of a float by 2, 3, 4 or 5 is exact in double (<= 27 significant bits), and fma(a, b, c) with an
+// exact a*b rounds exactly like (a*b) + c: those products are fused (13 fp64 operations instead of 16);
+// t*c3, t*c2 and (0.5*t)*c1 are inexact products and stay separate.
 __device__ __forceinline__ float keys_cubic(float v0, float v1, float v2, float v3, float t)
 {
     const float d20 = v2 - v0;
     const float d12 = v1 - v2;
     const double td = (double)t;
-    const double c3 = 3.0 * (double)d12 + (double)v3 - (double)v0;
-    const double c2 = 2.0 * (double)v0 - 5.0 * (double)v1 + 4.0 * (double)v2 - (double)v3 + td * c3;
+    const double e0 = (double)v0, e1 = (double)v1, e2 = (double)v2, e3 = (double)v3;
+    const double c3 = __builtin_fma(3.0, (double)d12, e3) - e0;
+    const double c2 = (__builtin_fma(4.0, e2, __builtin_fma(-5.0, e1, 2.0 * e0)) - e3) + td * c3;
     const double c1 = (double)d20 + td * c2;
-    return (float)((double)v1 + 0.5 * td * c1);
+    return (float)(e1 + 0.5 * td * c1);
 }
 
 // :113-131,:199-236: 16 gathers, four column cubics along y, one cubic along x.
