@@ -48,6 +48,8 @@ struct GrowDir {                      // per growing: device pointers (array in 
     const float *seed_flow;           // [2][pe]
     int nseeds;
     int heap_cap;
+    int nx, ny;                       // size of the domain this growing runs on (the frame, or one partition of it)
+    size_t pe;                        // plane stride of `planes`, `out`, `seed_flow`
 };
 
 struct GrowShared {
@@ -558,11 +560,13 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
 }
 
 // mode 0: the seed pass of insert_initial_seeds (:764-783); mode 1: local_growing (:899-937).
-__device__ __forceinline__ void grow_body(GrowShared &sm, const GrowDir *__restrict__ dirs, size_t pe, int nx, int ny, int mode,
-                                          int iteration, int wr, int max_iter_patch, int budget)
+__device__ __forceinline__ void grow_body(GrowShared &sm, const GrowDir *__restrict__ dirs, int mode, int iteration, int wr,
+                                          int max_iter_patch, int budget)
 {
     const GrowDir D = dirs[blockIdx.x];
     const int t = threadIdx.x;
+    const int nx = D.nx, ny = D.ny;
+    const size_t pe = D.pe;
     int heap_size = 0, seed_pos = 0;
     long long pops = 0, solves = 0, fills = 0;
     long long cyc[3] = { 0, 0, 0 };
@@ -645,19 +649,18 @@ __device__ __forceinline__ void grow_body(GrowShared &sm, const GrowDir *__restr
 // 4 growings per CU); the dense build is held to 128 VGPRs (a few spills, ~8 % slower per growing) and fits 8 per
 // CU.  Measured on 256x192 pairs: 512 pairs 26.7 M windows/s with the default build, 1024 pairs 28.6 M (default)
 // vs 35.7 M (dense).  The host picks by the number of growings.
-__global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__restrict__ dirs, size_t pe, int nx, int ny,
-                                                           int mode, int iteration, int wr, int max_iter_patch, int budget)
+__global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr,
+                                                           int max_iter_patch, int budget)
 {
     __shared__ GrowShared sm;
-    grow_body(sm, dirs, pe, nx, ny, mode, iteration, wr, max_iter_patch, budget);
+    grow_body(sm, dirs, mode, iteration, wr, max_iter_patch, budget);
 }
 
 __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void grow_kernel_dense(const GrowDir *__restrict__ dirs, size_t pe, int nx, int ny, int mode, int iteration, int wr,
-                       int max_iter_patch, int budget)
+void grow_kernel_dense(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr, int max_iter_patch, int budget)
 {
     __shared__ GrowShared sm;
-    grow_body(sm, dirs, pe, nx, ny, mode, iteration, wr, max_iter_patch, budget);
+    grow_body(sm, dirs, mode, iteration, wr, max_iter_patch, budget);
 }
 
 // Test hook: replays push (1) / pop (0) operations on the device queue with one wavefront.

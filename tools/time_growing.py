@@ -20,9 +20,13 @@ ap.add_argument("--pairs", type=int, default=1)
 ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--budget", type=int, default=16384)
 ap.add_argument("--loc_it", type=int, default=3)
+ap.add_argument("--hard", action="store_true", help="the final/hard example pair (large motion) instead of clean/easy")
 a = ap.parse_args()
 crop = tuple(int(v) for v in a.crop.split(",")) if a.crop else None
 i0, i1 = util.sintel_pair(crop)
+if a.hard:
+    i0 = util.load_rgb_planar(os.path.join(util.GOLDEN, "sintel_final_hard_frame_0002.png"), crop)
+    i1 = util.load_rgb_planar(os.path.join(util.GOLDEN, "sintel_final_hard_frame_0003.png"), crop)
 ctx = F.Context()
 i0n, i1n = ctx.preprocess_local(i0, i1)
 h, w = i0n.shape
