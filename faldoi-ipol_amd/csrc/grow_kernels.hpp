@@ -49,6 +49,8 @@ struct GrowDir {                      // per growing: device pointers (array in 
     int nseeds;
     int heap_cap;
     int nx, ny;                       // size of the domain this growing runs on (the frame, or one partition of it)
+    int shadow;                       // 1: keep the duals and the out-of-window divergence statements in HBM (partitions)
+    int pad;
     size_t pe;                        // plane stride of `planes`, `out`, `seed_flow`
 };
 
@@ -251,7 +253,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
 // during the call (src/energy_model.cpp:744-745), and the data energy is weighted (:227, a double product).
 __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_t pe, int nx, int ny, int ii, int ij, int ei,
                                               int ej, int max_iter_patch, float &u1, float &u2, const float *weight, int iiw,
-                                              int ijw, int wr_call)
+                                              int ijw, int wr_call, int shadow)
 {
     const int pw = ei - ii, ph = ej - ij, t = threadIdx.x;
     const bool act = t < pw * ph;
@@ -365,6 +367,28 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         base[L_U2 * pe + p] = u2;
         D1[p] = d1;
         D2[p] = d2;
+        if (shadow) {
+            // Partitioned runs change the domain between growings, so what is a border entry now may be an interior
+            // (stale-read) entry later: the duals are kept in HBM and the statements of divergence_patch that land on
+            // the DOMAIN's row 0 / column 0 / column nx-1 outside the window (src/utils.cpp:90,98,101) are carried out.
+            // They read duals this call does not touch, so once, after the last iteration, is the same as every time.
+            float *X11 = base + L_X11 * pe, *X12 = base + L_X12 * pe, *X21 = base + L_X21 * pe, *X22 = base + L_X22 * pe;
+            X11[p] = x11; X12[p] = x12; X21[p] = x21; X22[p] = x22;
+            if (k_in && first_row && ij > 0) {                                    // :90  div[k] = v1[k] - v1[k-1] + v2[k]
+                D1[k] = X11[k] - X11[k - 1] + X12[k];
+                D2[k] = X21[k] - X21[k - 1] + X22[k];
+            }
+            if (l_in && first_col && ii > 0) {                                    // :98  p1 = l*nx
+                const int p1 = l * nx;
+                D1[p1] = X11[p1] + X12[p1] - X12[p1 - nx];
+                D2[p1] = X21[p1] + X22[p1] - X22[p1 - nx];
+            }
+            if (l_in && last_col && ei < nx) {                                    // :101 p2 = (l+1)*nx - 1
+                const int p2 = (l + 1) * nx - 1;
+                D1[p2] = -X11[p2 - 1] + X12[p2] - X12[p2 - nx];
+                D2[p2] = -X21[p2 - 1] + X22[p2] - X22[p2 - nx];
+            }
+        }
         const float ar = sm.a[ridx], ad = sm.a[didx], br = sm.b[ridx], bd = sm.b[didx];
         const float u1x = !last_col ? ar - u1 : 0.0f, u1y = !last_row ? ad - u1 : 0.0f;
         const float u2x = !last_col ? br - u2 : 0.0f, u2y = !last_row ? bd - u2 : 0.0f;
@@ -529,7 +553,7 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
     }
     const long long c1 = clock64();
     const int iiw = (i - wr < 0) ? -(i - wr) : 0, ijw = (j - wr < 0) ? -(j - wr) : 0;    // get_relative_index_weight :551-557
-    const float ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2, D.weight, iiw, ijw, wr);
+    const float ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2, D.weight, iiw, ijw, wr, D.shadow);
     const long long c2 = clock64();
     if (t < 64) {                                                                 // insert_candidates :497-537
         const float ener0 = lane_read(ener, 0);                                   // lane 0 summed the energy

@@ -13,7 +13,8 @@
 // image under a name it has no encoder for: ASCII "P2" with one C99 hex-float per line
 // (src/iio.c:3505-3511).  Like the reference, the local step ignores the values of
 // the -p file (src/energy_model.cpp:704-709).
-// Built: -m 0 (TV-l2 coupled) and -m 1 (TV-l2 coupled with weights), -split_img 0.  Other functionals / partitioning are refused loudly.
+// Built: -m 0 (TV-l2 coupled) and -m 1 (TV-l2 coupled with weights), with or without image partitions
+// (-split_img 1 -h_parts H -v_parts V; not together with saliency maps).  Other functionals are refused loudly.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,8 +63,8 @@ int main(int argc, char *argv[])
         const int loc_it = std::stoi(pick_option(args, "loc_it", "3"));
         const int max_pch_it = std::stoi(pick_option(args, "max_pch_it", "4"));
         const int split_img = std::stoi(pick_option(args, "split_img", "0"));
-        (void)pick_option(args, "h_parts", "3");
-        (void)pick_option(args, "v_parts", "2");
+        const int h_parts = std::stoi(pick_option(args, "h_parts", "3"));
+        const int v_parts = std::stoi(pick_option(args, "v_parts", "2"));
         const float fb_thresh = std::stof(pick_option(args, "fb_thresh", "2"));
         const int partial_res = std::stoi(pick_option(args, "partial_res", "0"));
         const int verbose = std::stoi(pick_option(args, "verbose", "0"));
@@ -79,7 +80,6 @@ int main(int argc, char *argv[])
                             "weights -m 1)\n", method);
             return 2;
         }
-        if (split_img != 0) { fprintf(stderr, "ERROR: image partitioning (-split_img 1) is not part of this build\n"); return 2; }
         if (partial_res != 0) fprintf(stderr, "warning: -partial_res is ignored (no partial results are written)\n");
 
         std::vector<std::string> files;
@@ -128,7 +128,7 @@ int main(int argc, char *argv[])
         faldoi_local_params prm;
         faldoi_local_default_params(&prm);
         prm.w_radio = w_radio; prm.iterations_of = loc_it; prm.max_iter_patch = max_pch_it; prm.epsilon = fb_thresh;
-        prm.verbose = verbose; prm.method = method;
+        prm.verbose = verbose; prm.method = method; prm.split_img = split_img; prm.h_parts = h_parts; prm.v_parts = v_parts;
         if (budget > 0) prm.budget = budget;
         faldoi_ctx *ctx = nullptr;
         if (faldoi_ctx_create(gpu, &ctx)) { fprintf(stderr, "ERROR: no usable GPU: %s\n", faldoi_last_error()); return 3; }

@@ -231,7 +231,7 @@ int faldoi_tvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, floa
 /* src/global_faldoi.cpp:906-932 image_to_lab: planar R,G,B (0..255) -> planar L,a*,b* (host, libm). */
 int faldoi_image_to_lab(const float *rgb, int nx, int ny, float *lab);
 
-/* ---- the local step: match_growing_variational, src/local_faldoi.cpp:1060-1741 (-m 0, -split_img 0) ----
+/* ---- the local step: match_growing_variational, src/local_faldoi.cpp:1060-1741 (-m 0 / 1, -split_img 0 / 1) ----
  * Seeds -> priority-queue growing (forward and backward) -> forward-backward pruning -> re-seeding,
  * `iterations_of` times, then a last forward growing.  Argument order follows the reference function:
  * go / ba = seed flows (2 planes each, NaN = no seed), i0 / i1 = frames (planar, pd channels, 0..255; or
@@ -248,6 +248,9 @@ typedef struct faldoi_local_params {
     int budget;           /* windows per growing per kernel launch (host relaunches until the queue is empty) */
     int verbose;
     int method;           /* -m: 0 = TV-l2 coupled (M_TVL1), 1 = TV-l2 coupled with weights (M_TVL1_W, src/tvl2w_model.cpp) */
+    int split_img;        /* -split_img: 1 = grow on image partitions from local iteration 1 on (src/aux_partitions.cpp); one pair per call */
+    int h_parts;          /* -h_parts, HOR_PARTS 3 (src/parameters.h:69) */
+    int v_parts;          /* -v_parts, VER_PARTS 2 (:70) */
 } faldoi_local_params;
 typedef struct faldoi_local_stats {
     long long pops[2];    /* candidates popped, forward / backward (summed over the batch) */

@@ -38,6 +38,7 @@ struct Direction {                 // OpticalFlowData + Tvl2CoupledOFStuff + the
     int w, h;
     const float *src, *dst;        // normalised source / target frame (i0n,i1n forward; i1n,i0n backward)
     const float *sal;              // saliency or NULL (= 1)
+    std::vector<float> own_src, own_dst;   // partition crops of the frames (empty for the whole image)
     std::vector<float> dstx, dsty; // centred gradient of the target frame (prepare_stuff)
     std::vector<float> u;          // ofD->u1 | u2
     std::vector<float> state;      // xi11..xi22, div1, div2 (persistent, see faldoi_oracle_local.c)
@@ -253,9 +254,120 @@ extern "C" double orc_fb_consistency_check(const float *in0, const float *in1, i
 /* i0n, i1n: normalised frames (orc_preprocess_local).  go, ba: seed flows (2 planes, NaN = no seed).
  * sal0, sal1: saliency planes or NULL.  out_flow (2 planes) and ene_val receive oft0 / ene_Go.
  * stats (may be NULL): [0..2] forward pops / patch solves / Poisson fills, [3..5] backward. */
-extern "C" void orc_local_faldoi(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,
-                                 const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
-                                 int method, float *out_flow, float *ene_val, long *stats)
+namespace {
+
+// ---- image partitions (-split_img 1), src/aux_partitions.cpp ----
+struct Partition {
+    int w, h, ox, oy;
+    Direction d[2];
+    long queued[2];                // queue_Go_size / queue_Ba_size: never reset (src/aux_partitions.cpp:1998,2021)
+};
+
+// init_subimage_partitions, src/aux_partitions.cpp:47-270: a cols x rows grid; the remainders go to the last column / row
+void make_partitions(std::vector<Partition> &P, int cols, int rows, const Direction *img)
+{
+    const int w = img[0].w, h = img[0].h;
+    P.resize((size_t)cols * rows);
+    const int sw = w / cols, sh = h / rows;
+    for (int r = 0; r < rows; r++)
+        for (int c = 0; c < cols; c++) {
+            Partition &p = P[(size_t)r * cols + c];
+            p.w = sw + (c == cols - 1 ? w % cols : 0);
+            p.h = sh + (r == rows - 1 ? h % rows : 0);
+            p.ox = c * sw;
+            p.oy = r * sh;
+            p.queued[0] = p.queued[1] = 0;
+            for (int k = 0; k < 2; k++) {
+                Direction &d = p.d[k];
+                const size_t n = (size_t)p.w * p.h;
+                d.own_src.resize(n); d.own_dst.resize(n);
+                for (int j = 0; j < p.h; j++)
+                    for (int i = 0; i < p.w; i++) {
+                        d.own_src[(size_t)j * p.w + i] = img[k].src[(size_t)(p.oy + j) * w + p.ox + i];
+                        d.own_dst[(size_t)j * p.w + i] = img[k].dst[(size_t)(p.oy + j) * w + p.ox + i];
+                    }
+                init_direction(d, d.own_src.data(), d.own_dst.data(), NULL, p.w, p.h, img[k].wr, img[k].max_iter_patch, img[k].method);
+            }
+        }
+}
+
+// image_to_partitions, src/aux_partitions.cpp:2056-2156 (with update_of_data :285 and update_tvl2_stuffof :403):
+// every per-pixel state plane is copied between the image and the partitions, the gradients of the target frame
+// included (so a partition works on crops of the image's planes); to_part: the candidates are distributed too.
+void image_to_partitions(std::vector<Partition> &P, Direction *img, bool to_part)
+{
+    const int w = img[0].w;
+    const size_t n = (size_t)w * img[0].h;
+    for (Partition &p : P) {
+        const size_t m = (size_t)p.w * p.h;
+        for (int k = 0; k < 2; k++) {
+            Direction &g = img[k], &d = p.d[k];
+            for (int j = 0; j < p.h; j++)
+                for (int i = 0; i < p.w; i++) {
+                    const size_t a = (size_t)(p.oy + j) * w + p.ox + i, b = (size_t)j * p.w + i;
+                    if (to_part) {
+                        d.fixed[b] = g.fixed[a]; d.trust[b] = g.trust[a];
+                        d.u[b] = g.u[a]; d.u[m + b] = g.u[n + a];
+                        for (int q = 0; q < 6; q++) d.state[q * m + b] = g.state[q * n + a];
+                        d.dstx[b] = g.dstx[a]; d.dsty[b] = g.dsty[a];
+                        d.ene[b] = g.ene[a]; d.out[b] = g.out[a]; d.out[m + b] = g.out[n + a];
+                    } else {
+                        g.fixed[a] = d.fixed[b]; g.trust[a] = d.trust[b];
+                        g.u[a] = d.u[b]; g.u[n + a] = d.u[m + b];
+                        for (int q = 0; q < 6; q++) g.state[q * n + a] = d.state[q * m + b];
+                        g.dstx[a] = d.dstx[b]; g.dsty[a] = d.dsty[b];
+                        g.ene[a] = d.ene[b]; g.out[a] = d.out[b]; g.out[n + a] = d.out[m + b];
+                    }
+                }
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        if (to_part) {                                                   // update_candidate_queues :1970-2031
+            CandidateQueue tmp = img[k].queue;
+            while (!tmp.empty()) {
+                Candidate c = tmp.top();
+                const int i = c.i, j = c.j;
+                for (Partition &p : P)
+                    if (i >= p.ox && i <= p.ox + p.w - 1 && j >= p.oy && j <= p.oy + p.h - 1) {
+                        c.i = i >= p.w ? i - p.ox : i;                   // sic (:1992-1993): not `i - off_x` whenever i < width
+                        c.j = j >= p.h ? j - p.oy : j;
+                        p.d[k].queue.push(c);
+                        p.queued[k]++;
+                    }
+                tmp.pop();
+            }
+        } else {
+            img[k].queue = CandidateQueue();
+        }
+    }
+}
+
+bool any_empty_queues(const std::vector<Partition> &P)                   // :2161-2180
+{
+    for (const Partition &p : P)
+        if (p.queued[0] == 0 || p.queued[1] == 0) return true;
+    return false;
+}
+
+void prune_and_reseed(Direction *d, int w, int h, float fb_thresh)       // :1231-1266
+{
+    fb_consistency_check(d[0].out.data(), d[1].out.data(), d[0].trust.data(), w, h, fb_thresh);   // pruning_method :209
+    fb_consistency_check(d[1].out.data(), d[0].out.data(), d[1].trust.data(), w, h, fb_thresh);
+    for (int k = 0; k < 2; k++) {
+        delete_not_trustable_candidates(d[k]);
+        insert_potential_candidates(d[k]);
+    }
+}
+
+}  // namespace
+
+/* split_img = 0: whole-image growings.  split_img = 1 (-split_img 1 -h_parts H -v_parts V): local iteration 0 on the
+ * whole image, odd iterations on an H x V grid of partitions, even ones on a V x H grid, the last growing on the H x V
+ * grid (src/local_faldoi.cpp:1284-1700).  stats as before, partitions included. */
+extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,
+                                       const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
+                                       int method, int split_img, int h_parts, int v_parts, float *out_flow, float *ene_val,
+                                       long *stats)
 {
     const size_t n = (size_t)w * h;
     Direction d[2];
@@ -263,21 +375,60 @@ extern "C" void orc_local_faldoi(const float *i0n, const float *i1n, const float
     init_direction(d[1], i1n, i0n, sal1, w, h, wr, max_iter_patch, method);
 #pragma omp parallel for num_threads(2)
     for (int k = 0; k < 2; k++) insert_initial_seeds(d[k], k == 0 ? go : ba);     // :1130-1139
-    for (int it = 0; it < loc_it; it++) {                                          // :1184-1282
-#pragma omp parallel for num_threads(2)
-        for (int k = 0; k < 2; k++) local_growing(d[k], it);
-        fb_consistency_check(d[0].out.data(), d[1].out.data(), d[0].trust.data(), w, h, fb_thresh);   // pruning_method :209
-        fb_consistency_check(d[1].out.data(), d[0].out.data(), d[1].trust.data(), w, h, fb_thresh);
-        for (int k = 0; k < 2; k++) {
-            delete_not_trustable_candidates(d[k]);
-            insert_potential_candidates(d[k]);
-        }
+    std::vector<Partition> PA, PB;
+    if (split_img) {                                                               // :1160-1172
+        make_partitions(PA, h_parts, v_parts, d);
+        make_partitions(PB, v_parts, h_parts, d);
     }
-    local_growing(d[0], loc_it);                                                   // :1703
+    auto grow_partitions = [&](std::vector<Partition> &P, int it, int ndir) {
+        const int count = (int)P.size() * ndir;
+#pragma omp parallel for schedule(dynamic)
+        for (int q = 0; q < count; q++) local_growing(P[q / ndir].d[q % ndir], it);
+    };
+    for (int it = 0; it < loc_it; it++) {                                          // :1184-1640
+        if (!split_img || it == 0) {
+#pragma omp parallel for num_threads(2)
+            for (int k = 0; k < 2; k++) local_growing(d[k], it);
+        } else {
+            std::vector<Partition> &P = (it % 2 != 0) ? PA : PB;
+            image_to_partitions(P, d, true);
+            if (!any_empty_queues(P)) {
+                grow_partitions(P, it, 2);
+                image_to_partitions(P, d, false);
+            } else {                                                               // :1349-1370: whole image instead
+#pragma omp parallel for num_threads(2)
+                for (int k = 0; k < 2; k++) local_growing(d[k], it);
+            }
+        }
+        prune_and_reseed(d, w, h, fb_thresh);
+    }
+    if (split_img) {                                                               // :1642-1693
+        image_to_partitions(PA, d, true);
+        if (!any_empty_queues(PA)) {
+            grow_partitions(PA, loc_it, 1);
+            image_to_partitions(PA, d, false);
+        } else {
+            local_growing(d[0], loc_it);
+        }
+    } else {
+        local_growing(d[0], loc_it);                                               // :1703
+    }
     memcpy(out_flow, d[0].out.data(), sizeof(float) * 2 * n);
     memcpy(ene_val, d[0].ene.data(), sizeof(float) * n);
-    if (stats)
+    if (stats) {
         for (int k = 0; k < 2; k++) { stats[3 * k] = d[k].pops; stats[3 * k + 1] = d[k].solves; stats[3 * k + 2] = d[k].fills; }
+        for (std::vector<Partition> *P : { &PA, &PB })
+            for (Partition &p : *P)
+                for (int k = 0; k < 2; k++) { stats[3 * k] += p.d[k].pops; stats[3 * k + 1] += p.d[k].solves; stats[3 * k + 2] += p.d[k].fills; }
+    }
+}
+
+extern "C" void orc_local_faldoi(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,
+                                 const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
+                                 int method, float *out_flow, float *ene_val, long *stats)
+{
+    orc_local_faldoi_split(i0n, i1n, go, ba, sal0, sal1, w, h, wr, loc_it, max_iter_patch, fb_thresh, method, 0, 1, 1, out_flow,
+                           ene_val, stats);
 }
 
 /* prepare_stuff's image part for TV-l2 coupled, src/energy_model.cpp:660-684 */

@@ -118,8 +118,6 @@ def test_local_faldoi_cli_argument_handling(bins, tmp_path):
     base = [exe, str(ims), str(s0), str(s0), str(tmp_path / "o.flo"), str(tmp_path / "sim.tiff")]
     r = subprocess.run(base + ["-m", "2"], capture_output=True, text=True)          # functional not built
     assert r.returncode == 2 and "not available" in r.stderr
-    r = subprocess.run(base + ["-split_img", "1"], capture_output=True, text=True)  # partitioning not built
-    assert r.returncode == 2 and "partitioning" in r.stderr
     r = subprocess.run(base + ["occ.png"], capture_output=True, text=True)          # occlusion outputs not built
     assert r.returncode == 2
     ims3 = tmp_path / "ims3.txt"

@@ -20,6 +20,7 @@ ap.add_argument("--pairs", type=int, default=1)
 ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--budget", type=int, default=16384)
 ap.add_argument("--loc_it", type=int, default=3)
+ap.add_argument("--split", default="", help="H,V: image partitions (-split_img 1 -h_parts H -v_parts V)")
 ap.add_argument("--hard", action="store_true", help="the final/hard example pair (large motion) instead of clean/easy")
 a = ap.parse_args()
 crop = tuple(int(v) for v in a.crop.split(",")) if a.crop else None
@@ -41,8 +42,9 @@ for src, dst in ((i0n, i1n), (i1n, i0n)):
 go, ba = seeds
 print("size %dx%d, seeds %d / %d" % (w, h, np.isfinite(go[0]).sum(), np.isfinite(ba[0]).sum()), flush=True)
 t = time.time()
+split = dict(split_img=1, h_parts=int(a.split.split(",")[0]), v_parts=int(a.split.split(",")[1])) if a.split else {}
 if a.pairs == 1:
-    out, ene, st = ctx.match_growing(i0, i1, go, ba, budget=a.budget, iterations_of=a.loc_it)
+    out, ene, st = ctx.match_growing(i0, i1, go, ba, budget=a.budget, iterations_of=a.loc_it, **split)
 else:
     outs, enes, st = ctx.match_growing_batch([i0] * a.pairs, [i1] * a.pairs, [go] * a.pairs, [ba] * a.pairs,
                                             budget=a.budget, iterations_of=a.loc_it)
@@ -58,7 +60,7 @@ print("FB kept:", [round(v, 4) for v in st.fb_kept[:2 * a.loc_it]], "finite:", f
 if a.cpu:
     from oracle import oracle as O
     t = time.time()
-    want, wene, ost = O.local_faldoi(i0n, i1n, go, ba, loc_it=a.loc_it)
+    want, wene, ost = O.local_faldoi(i0n, i1n, go, ba, loc_it=a.loc_it, **split)
     dt = time.time() - t
-    print("CPU checker (2 threads): %.2f s => %.1f k windows/s; bit-identical flow: %s, energy: %s"
+    print("CPU checker (forward || backward; partitions on up to 16 threads): %.2f s => %.1f k windows/s; bit-identical flow: %s, energy: %s"
           % (dt, (ost[1] + ost[4]) / dt / 1e3, util.bits_equal(out, want), util.bits_equal(ene if a.pairs == 1 else enes[0], wene)))
