@@ -573,6 +573,12 @@ def test_three_cli_pipeline_matches_cpu_path(ctx, oracle, tmp_path):
     oracle.lib().orc_tvl1_global(g0, g1.copy(), u[0], u[1], xi[0], xi[1], xi[2], xi[3], 40, 0.3, 0.125, 0.01, w, h, 5, 400, 1, its, errs)
     got = F.flo.read_flo(str(tmp_path / "final.flo"))
     assert bits_equal(got, u), mismatch_report(got, u)
+    # partitioned growing through the executable
+    r = run(bins["local_faldoi"], tmp_path / "ims.txt", tmp_path / "s0.flo", tmp_path / "s1.flo", tmp_path / "local_split.flo",
+            tmp_path / "sim_split.tiff", "-split_img", 1, "-h_parts", 2, "-v_parts", 2)
+    assert r.returncode == 0, r.stderr + r.stdout
+    want_split, _, _ = oracle.local_faldoi(a, b, go, ba, split_img=1, h_parts=2, v_parts=2)
+    assert bits_equal(F.flo.read_flo(str(tmp_path / "local_split.flo")), want_split)
     # the one-process driver (no intermediate files) gives the same bytes; "sift" layout = match_cli columns 2,1,6,5
     for name in ("m0.txt", "m1.txt"):
         with open(tmp_path / name) as f, open(tmp_path / ("raw_" + name), "w") as g:
