@@ -79,6 +79,11 @@ struct GrowShared {
 // the early exit (`maxupdate < 1e-10` after a sweep: the later versions are simply not used) are
 // the reference's.  Returns this thread's filled (u1, u2) (threads outside the window: 0).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_read(float v, int lane)    // lane: wave-uniform
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -110,6 +115,16 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
 #pragma unroll
     for (int s = 1; s < kElapLevels; ++s) {                         // zoom_out_by_factor_two :160-175
         const int iw = ws[s - 1], ih = hs[s - 1], ow = ws[s];
+        if (iw * ih == 1) {                                         // 1x1 from 1x1: the four clamped samples are the pixel itself
+            if (lane == 0) {
+                const float v = in[off[s - 1]];
+                float m = 0;
+                m += v; m += v; m += v; m += v;
+                in[off[s]] = __builtin_isfinite(v) ? m / 4 : __builtin_nanf("");
+            }
+            wave_sync();
+            continue;
+        }
         if (lane < ow * hs[s]) {
             const int zi = lane % ow, zj = lane / ow;
             const float *x = in + off[s - 1];
@@ -159,8 +174,9 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         const int ic = lane_on ? i : 0;
         unsigned holes = 0;                                         // bit j: pixel (i, j) of this lane's column is a hole
         if (lane_on) {
+            const int hmax = (kPatchMax + (1 << s) - 1) >> s;       // level s of an at most 11-row window (constant once s is unrolled)
 #pragma unroll
-            for (int j = 0; j < kPatchMax; ++j) {                   // clamped row: the loads do not depend on h
+            for (int j = 0; j < hmax; ++j) {                        // clamped row: the loads do not depend on h
                 const float xv = x[(j < h ? j : h - 1) * w + i];
                 holes |= (j < h && __builtin_isnan(xv)) ? (1u << j) : 0u;
             }
@@ -219,12 +235,15 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
             j = jn;
             wave_sync();
         }
-#pragma unroll
-        for (int q = 8; q > 0; q >>= 1) {                           // max over each 16-lane group
-            const float other = __shfl_xor(mx, q, 64);
-            mx = other > mx ? other : mx;
+        // max over each 16-lane group: four row shifts accumulate it in the group's last lane (updates are >= 0, and
+        // a shifted-in 0 at the row start is neutral)
+        {
+            float o1 = __builtin_amdgcn_update_dpp(0.0f, mx, 0x111, 0xf, 0xf, true); mx = o1 > mx ? o1 : mx;    // row_shr:1
+            float o2 = __builtin_amdgcn_update_dpp(0.0f, mx, 0x112, 0xf, 0xf, true); mx = o2 > mx ? o2 : mx;    // row_shr:2
+            float o4 = __builtin_amdgcn_update_dpp(0.0f, mx, 0x114, 0xf, 0xf, true); mx = o4 > mx ? o4 : mx;    // row_shr:4
+            float o8 = __builtin_amdgcn_update_dpp(0.0f, mx, 0x118, 0xf, 0xf, true); mx = o8 > mx ? o8 : mx;    // row_shr:8
         }
-        const float m1 = __shfl(mx, 0, 64), m2 = __shfl(mx, 16, 64);
+        const float m1 = lane_read(mx, 15), m2 = lane_read(mx, 31);
         const int kfin = ((double)m1 < 1e-10) ? 1 : (((double)m2 < 1e-10) ? 2 : 3);     // :66-67
         for (int q = lane; q < w * h; q += 64) fin[o + q] = sm.ver[c][kfin][o + q];
         wave_sync();
@@ -439,11 +458,6 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
 // ---------------------------------------------------------------------------------------------
 typedef float cand4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) cand4 *heap_ptr;      // the queue lives in global memory: plain global loads
-
-__device__ __forceinline__ float lane_read(float v, int lane)    // lane: wave-uniform
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
 
 __device__ __forceinline__ void heap_sift_up_wave(heap_ptr h, int hole, const cand4 value)
 {
