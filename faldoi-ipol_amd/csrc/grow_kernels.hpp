@@ -62,6 +62,7 @@ struct GrowShared {
     float x[4][kPatchThreads];        // duals of the current iteration
     alignas(16) float t[kPatchThreads];   // energy terms
     int err[4];                       // max |du|^2 (float bits) per wavefront, double-buffered
+    int res[2];                       // harmonic fill: offset of each channel's level-0 result from ver[c][0]
     int cur[4];                       // {have, i, j, pixel}
     int flag;
 };
@@ -139,6 +140,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         }
         wave_sync();
     }
+    const float *coarse = fin;                                      // solution of the level below (level-relative indexing)
 #pragma unroll
     for (int s = kElapLevels - 1; s >= 0; --s) {
         const int w = ws[s], h = hs[s], o = off[s];
@@ -148,7 +150,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
             if (lane == 0) {
                 float v = x[0];
                 if (!__builtin_isfinite(v)) {
-                    v = (s < kElapLevels - 1) ? fin[off[s + 1]] : 0.0f;
+                    v = (s < kElapLevels - 1) ? coarse[0] : 0.0f;
                     for (int it = 0; it < 3; ++it) {
                         const float lap = -4 * v + v + v + v + v;
                         const float nw = v + 0.4f * lap;
@@ -159,15 +161,16 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
                 }
                 fin[o] = v;
             }
+            coarse = fin + o;
             wave_sync();
             continue;
         }
         for (int q = lane; q < w * h; q += 64) {                    // :113-114 with the initialisation of :204-222
             float v = x[q];
-            float coarse = 0.0f;                                    // coarsest level starts from zero
+            float coarse_v = 0.0f;                                  // coarsest level starts from zero
             if (s < kElapLevels - 1)                                // round((i - 0.5) / 2) == i / 2 for i >= 0
-                coarse = px_clamp(fin + off[s + 1], ws[s + 1], hs[s + 1], (q % w) >> 1, (q / w) >> 1);
-            if (!__builtin_isfinite(v)) v = coarse;
+                coarse_v = px_clamp(coarse, ws[s + 1], hs[s + 1], (q % w) >> 1, (q / w) >> 1);
+            if (!__builtin_isfinite(v)) v = coarse_v;
             sm.ver[c][0][o + q] = v; sm.ver[c][1][o + q] = v; sm.ver[c][2][o + q] = v; sm.ver[c][3][o + q] = v;
         }
         const bool lane_on = g < 3 && i < w;
@@ -185,8 +188,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         const unsigned holes_left = (unsigned)__builtin_amdgcn_update_dpp(0, (int)holes, 0x111, 0xf, 0xf, true);
         wave_sync();
         if (__builtin_amdgcn_ballot_w64(holes != 0u) == 0ull) {     // no hole at this level: the sweeps change nothing
-            for (int q = lane; q < w * h; q += 64) fin[o + q] = sm.ver[c][0][o + q];
-            wave_sync();
+            coarse = sm.ver[c][0] + o;
             continue;
         }
         const float *y0 = sm.ver[c][0] + o;                         // initial state: the value of every non-hole
@@ -245,15 +247,15 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         }
         const float m1 = lane_read(mx, 15), m2 = lane_read(mx, 31);
         const int kfin = ((double)m1 < 1e-10) ? 1 : (((double)m2 < 1e-10) ? 2 : 3);     // :66-67
-        for (int q = lane; q < w * h; q += 64) fin[o + q] = sm.ver[c][kfin][o + q];
-        wave_sync();
+        coarse = sm.ver[c][kfin] + o;                               // the version the reference stops at
     }
+    if (lane == 0) sm.res[c] = (int)(coarse - sm.ver[c][0]);        // where this channel's level-0 solution lies
     __syncthreads();
     u1 = 0.0f;
     u2 = 0.0f;
     if (t < pw * ph) {
-        u1 = sm.fin[0][t];
-        u2 = sm.fin[1][t];
+        u1 = sm.ver[0][0][sm.res[0] + t];
+        u2 = sm.ver[1][0][sm.res[1] + t];
     }
 }
 
