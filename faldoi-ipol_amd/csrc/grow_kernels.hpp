@@ -430,12 +430,18 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         const float4 *t4 = reinterpret_cast<const float4 *>(sm.t);
 #pragma unroll
         for (int q = 0; q < (kPatchMax * kPatchMax + 3) / 4; ++q) v[q] = t4[q];
+        if (m == kPatchMax * kPatchMax) {                // the interior case: 121 plain additions
 #pragma unroll
-        for (int q = 0; q < (kPatchMax * kPatchMax + 3) / 4; ++q) {
-            if (4 * q + 0 < m) ener += v[q].x;
-            if (4 * q + 1 < m) ener += v[q].y;
-            if (4 * q + 2 < m) ener += v[q].z;
-            if (4 * q + 3 < m) ener += v[q].w;
+            for (int q = 0; q < kPatchMax * kPatchMax / 4; ++q) { ener += v[q].x; ener += v[q].y; ener += v[q].z; ener += v[q].w; }
+            ener += v[kPatchMax * kPatchMax / 4].x;
+        } else {
+#pragma unroll
+            for (int q = 0; q < (kPatchMax * kPatchMax + 3) / 4; ++q) {
+                if (4 * q + 0 < m) ener += v[q].x;
+                if (4 * q + 1 < m) ener += v[q].y;
+                if (4 * q + 2 < m) ener += v[q].z;
+                if (4 * q + 3 < m) ener += v[q].w;
+            }
         }
         ener = (float)((double)ener / (m * 1.0));
     }
