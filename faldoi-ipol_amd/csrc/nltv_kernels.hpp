@@ -310,6 +310,15 @@ __global__ __launch_bounds__(256) void tc_warp_kernel(float *__restrict__ base, 
     base[C_UB2 * pe + p] = u2;
 }
 
+// Loop control of one warp, on the device: the host queues several iterations at a time; once the stop test has
+// been decided (or cannot be decided without the serial sum) the kernels that are already queued do nothing.
+struct TcCtl {
+    int halt;            // 0: keep iterating; 1: stopped (test decided, or iteration cap); 2: the host must settle the test
+    int iters;           // iterations carried out in this warp
+    int pad[2];
+    double mean;         // mean |du|^2 of the last iteration (order-independent double sum)
+};
+
 // hypotf as the C library evaluates it for finite arguments: sqrt(x*x + y*y) in double, rounded to float
 __device__ __forceinline__ float hypotf_like_libm(float a, float b)
 {
@@ -318,8 +327,10 @@ __device__ __forceinline__ float hypotf_like_libm(float a, float b)
 }
 
 // forward_gradient of ubar (src/utils.cpp:285) + tvcsad_getD (:1424-1441)
-__global__ __launch_bounds__(256) void tc_dual_kernel(float *__restrict__ base, size_t pe, int nx, int ny, float tau)
+__global__ __launch_bounds__(256) void tc_dual_kernel(float *__restrict__ base, size_t pe, int nx, int ny, float tau,
+                                                      const TcCtl *__restrict__ ctl)
 {
+    if (ctl->halt) return;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= nx * ny) return;
     const int y = p / nx, x = p - y * nx;
@@ -343,9 +354,11 @@ __global__ __launch_bounds__(256) void tc_dual_kernel(float *__restrict__ base, 
 // a per-block double sum to part[] (order-independent to ~1e-13: enough to decide the test whenever the mean
 // is not within the rounding slack of a serial fp32 sum around tol^2; the host settles the rest exactly).
 __global__ __launch_bounds__(256) void tc_primal_kernel(float *__restrict__ base, size_t pe, int nx, int ny, float l_t,
-                                                        float theta, float tau, double *__restrict__ part)
+                                                        float theta, float tau, double *__restrict__ part,
+                                                        const TcCtl *__restrict__ ctl)
 {
     __shared__ double red[256];
+    if (ctl->halt) return;                                              // uniform over the grid
     const int i = blockIdx.x * 256 + threadIdx.x;
     float tt = 0.0f;
     if (i < nx * ny) {
@@ -381,9 +394,13 @@ __global__ __launch_bounds__(256) void tc_primal_kernel(float *__restrict__ base
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(256) void tc_sum_kernel(const double *__restrict__ part, int nparts, double *__restrict__ out)
+// Fixed-order double sum of the block partials, then the stop test of :1542 where it can be decided without knowing
+// the order of the reference's fp32 accumulation (`slack`: the relative error bound of a serial fp32 sum of n terms).
+__global__ __launch_bounds__(256) void tc_sum_kernel(const double *__restrict__ part, int nparts, TcCtl *__restrict__ ctl, double n,
+                                                     double tol2, double slack, int max_inner)
 {
     __shared__ double red[256];
+    if (ctl->halt) return;
     double acc = 0.0;
     for (int k = threadIdx.x; k < nparts; k += 256) acc += part[k];
     red[threadIdx.x] = acc;
@@ -392,7 +409,15 @@ __global__ __launch_bounds__(256) void tc_sum_kernel(const double *__restrict__ 
         if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = red[0];
+    if (threadIdx.x == 0) {
+        const double mean = red[0] / n;
+        const int it = ctl->iters + 1;
+        ctl->iters = it;
+        ctl->mean = mean;
+        if (mean * (1.0 - slack) > tol2) ctl->halt = (it >= max_inner) ? 1 : 0;          // err_D > tol^2 whatever the order
+        else if (mean * (1.0 + slack) < tol2) ctl->halt = 1;                             // err_D <= tol^2 whatever the order
+        else ctl->halt = 2;
+    }
 }
 
 }  // namespace faldoi
