@@ -84,6 +84,43 @@ def main():
         zi = np.empty((h, w), np.float32)
         R.ref_zoom_in(zo, zi, ww.value, hh.value, w, h)
         out["zoom_out_" + tag], out["zoom_in_" + tag] = zo, zi
+    # src/elap_recsep.c (harmonic window filling): windows with holes -> filled windows
+    for tag, (eh, ew, frac) in (("a", (11, 11, 0.4)), ("b", (11, 11, 0.93)), ("c", (7, 11, 0.6)), ("d", (3, 3, 0.5)), ("e", (2, 2, 0.5))):
+        x = (rng.standard_normal((2, eh, ew)) * 3).astype(np.float32)
+        x[:, rng.random((eh, ew)) < frac] = np.nan
+        o = np.empty_like(x)
+        R.ref_elap_recursive_separable(o, x.copy(), ew, eh, 2, 0.4, 3, 7)
+        out["elap_in_" + tag], out["elap_out_" + tag] = x, o
+    # local window operators on a sequence of overlapping windows (state carries over): plain and weighted
+    lh, lw = 30, 36
+    yy, xx = np.mgrid[0:lh, 0:lw].astype(np.float64)
+    l0 = (0.5 + 0.25 * np.sin(xx / 3.1) * np.cos(yy / 4.3) + 0.2 * np.sin((xx + 2 * yy) / 7.0)).astype(np.float32)
+    l1 = (0.5 + 0.25 * np.sin((xx - 0.8) / 3.1) * np.cos((yy + 0.5) / 4.3) + 0.2 * np.sin((xx - 0.8 + 2 * yy + 1.0) / 7.0)).astype(np.float32)
+    l1x, l1y = np.empty_like(l1), np.empty_like(l1)
+    R.ref_centered_gradient(l1, l1x, l1y, lw, lh)
+    wins = np.array([[5, 5, 5], [0, 0, 5], [lw - 1, lh - 1, 5], [20, 17, 5], [22, 18, 5], [1, lh - 2, 1], [0, 0, 1], [30, 2, 1],
+                     [lw - 1, 12, 5], [16, 12, 5], [17, 13, 5]], np.int32)            # centre column, row, radius
+    out["loc_i0"], out["loc_i1"], out["loc_wins"] = l0, l1, wins
+    u0 = (rng.standard_normal((2, lh, lw)) * 0.7).astype(np.float32)
+    out["loc_u0"] = u0
+    for tag in ("plain", "weighted"):
+        u = u0.copy()
+        ref = R.ref_local_tvl1w_create(lw, lh, 5) if tag == "weighted" else R.ref_local_tvl1_create(lw, lh)
+        eners = []
+        for ci, cj, wc in wins:
+            ii, ij, ei, ej = O.patch_index(int(wc), lw, lh, int(ci), int(cj))
+            if tag == "weighted":
+                e = R.ref_local_tvl1w_estimate(ref, l0, l1, l1x, l1y, u[0], u[1], ii, ij, ei, ej, 4, max(0, int(wc - ci)),
+                                               max(0, int(wc - cj)), int(wc))
+            else:
+                e = R.ref_local_tvl1_estimate(ref, l0, l1, l1x, l1y, u[0], u[1], ii, ij, ei, ej, 4)
+            eners.append(e)
+        (R.ref_local_tvl1w_destroy if tag == "weighted" else R.ref_local_tvl1_destroy)(ref)
+        out["loc_u_" + tag], out["loc_e_" + tag] = u, np.array(eners, np.float32)
+    for r in (1, 3, 5):
+        wv = np.zeros(2 * r + 1, np.float32)
+        R.ref_gaussian1d_weight(wv, r)
+        out["gw_%d" % r] = wv
     np.savez_compressed(os.path.join(HERE, "ref_primitives.npz"), **out)
     print("wrote ref_primitives.npz with", len(out), "arrays")
 
