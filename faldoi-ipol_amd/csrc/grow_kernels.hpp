@@ -29,7 +29,7 @@ struct GrowCtl {                      // per growing, in HBM
     int heap_size;
     int seed_pos;                     // next entry of the seed list (seed phase)
     int done;                         // 1 when the phase has nothing left to process
-    int pad;                          // set to 1 if a push did not fit (cannot happen: heap_cap is the worst case)
+    int overflow;                     // set to 1 if a push did not fit (cannot happen: heap_cap is the worst case)
     long long pops, solves, fills;    // statistics
     long long cyc_queue, cyc_fill, cyc_solve;   // shader-clock cycles spent by thread 0 in each part
 };
@@ -64,7 +64,6 @@ struct GrowShared {
     int err[4];                       // max |du|^2 (float bits) per wavefront, double-buffered
     int res[2];                       // harmonic fill: offset of each channel's level-0 result from ver[c][0]
     int cur[4];                       // {have, i, j, pixel}
-    int flag;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -587,7 +586,7 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
                 if (t == 0) D.ene[py * nx + px] = ener0;
                 const int wq = (py - ij) * pw + (px - ii);                        // the neighbour lies in the window
                 if (heap_size < D.heap_cap) heap_push_wave(D.heap, heap_size, px, py, sm.a[wq], sm.b[wq], new_ener);
-                else if (t == 0) D.ctl->pad = 1;
+                else if (t == 0) D.ctl->overflow = 1;
             }
         }
         const int g = j * nx + i, wq = (j - ij) * pw + (i - ii);                  // :718-726
