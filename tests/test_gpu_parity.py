@@ -803,3 +803,18 @@ def test_match_growing_with_image_partitions(ctx, oracle, crop, hp, vp, loc_it):
     sal = np.ones_like(a)
     with pytest.raises(F.FaldoiError):
         ctx.match_growing(a, b, go, ba, sal, sal, preprocessed=1, split_img=1)
+
+
+def test_match_growing_partitions_fall_back_to_the_whole_image(ctx, oracle):
+    # no backward seed at all: some partition queue never receives a candidate, so every partitioned iteration reverts
+    # to whole-image growings (src/local_faldoi.cpp:1349-1370) while the partitions' forward queues pile up unused
+    i0, i1 = sintel_pair((520, 210, 84, 60))
+    a, b = oracle.preprocess_local(i0, i1)
+    go, _ = _seed_flows(oracle, a, b, 0.02, seed=77)
+    none = np.full_like(go, np.nan)
+    want, wene, st = oracle.local_faldoi(a, b, go, none, split_img=1, h_parts=2, v_parts=2)
+    got, gene, gst = ctx.match_growing(a, b, go, none, preprocessed=1, split_img=1, h_parts=2, v_parts=2)
+    assert list(gst.solves) == [st[1], st[4]] and list(gst.pops) == [st[0], st[3]]
+    assert bits_equal(got, want), mismatch_report(got, want)
+    plain, _, _ = oracle.local_faldoi(a, b, go, none)
+    assert bits_equal(plain, want)                          # with the fall-back it is the unpartitioned run
