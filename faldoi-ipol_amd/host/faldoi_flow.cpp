@@ -10,7 +10,8 @@
 //                          scripts_python/auxiliar_faldoi_functions.py:19-30)
 //                    deep: columns 1-4 (cut_deep_list :32-45);  cut: already "x0 y0 x1 y1"
 //               [-local_out local.flo] [-sim_out sim_map]      keep the intermediate results
-//               [-wr 5] [-loc_it 3] [-max_pch_it 4] [-fb_thresh 2] [-w 5] [-verbose 0] [-gpu 0]
+//               [-m 0|1] [-wr 5] [-loc_it 3] [-max_pch_it 4] [-fb_thresh 2] [-split_img 0|1] [-h_parts 3] [-v_parts 2]
+//               [-w 5] [-verbose 0] [-gpu 0]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -65,12 +66,17 @@ int main(int argc, char *argv[])
         const int loc_it = std::stoi(pick_option(args, "loc_it", "3"));
         const int max_pch_it = std::stoi(pick_option(args, "max_pch_it", "4"));
         const float fb_thresh = std::stof(pick_option(args, "fb_thresh", "2"));
+        const int split_img = std::stoi(pick_option(args, "split_img", "0"));
+        const int h_parts = std::stoi(pick_option(args, "h_parts", "3"));
+        const int v_parts = std::stoi(pick_option(args, "v_parts", "2"));
+        const int local_method = std::stoi(pick_option(args, "m", "0"));       // 0 / 1: local functional; the global step uses TV-l2 either way (:2132)
         const int warps = std::stoi(pick_option(args, "w", std::to_string(FALDOI_DEFAULT_WARPS_GLOBAL)));
         const int verbose = std::stoi(pick_option(args, "verbose", "0"));
         const int gpu = std::stoi(pick_option(args, "gpu", "0"));
         if (args.size() != 5 || (matcher != "sift" && matcher != "deep" && matcher != "cut")) {
             fprintf(stderr, "usage: %s ims.txt matches_fwd.txt matches_bwd.txt out.flo [-matcher sift|deep|cut] [-local_out f.flo] "
-                            "[-sim_out f] [-wr 5] [-loc_it 3] [-max_pch_it 4] [-fb_thresh 2] [-w 5] [-verbose 0] [-gpu 0]\n", argv[0]);
+                            "[-sim_out f] [-m 0|1] [-wr 5] [-loc_it 3] [-max_pch_it 4] [-fb_thresh 2] [-split_img 0|1] [-h_parts 3] [-v_parts 2] "
+                            "[-w 5] [-verbose 0] [-gpu 0]\n", argv[0]);
             return 1;
         }
         std::vector<std::string> files;
@@ -105,6 +111,7 @@ int main(int argc, char *argv[])
         faldoi_local_params lp;
         faldoi_local_default_params(&lp);
         lp.w_radio = w_radio; lp.iterations_of = loc_it; lp.max_iter_patch = max_pch_it; lp.epsilon = fb_thresh; lp.verbose = verbose;
+        lp.split_img = split_img; lp.h_parts = h_parts; lp.v_parts = v_parts; lp.method = local_method;
         std::vector<float> u(2 * n), ene(n);
         faldoi_local_stats ls;
         if (faldoi_match_growing_variational(ctx, go.data(), ba.data(), i0.data.data(), i1.data.data(), nullptr, nullptr, w, h, pd,

@@ -785,20 +785,21 @@ def test_device_queue_pops_like_the_host_queue(ctx):
         assert np.array_equal(got, want), (levels, n, int(np.argmax(got != want)) if len(got) == len(want) else (len(got), len(want)))
 
 
-@pytest.mark.parametrize("crop,hp,vp,loc_it", [((400, 150, 100, 70), 3, 2, 3), ((100, 60, 91, 66), 2, 2, 2), ((700, 250, 72, 54), 1, 3, 3)])
-def test_match_growing_with_image_partitions(ctx, oracle, crop, hp, vp, loc_it):
+@pytest.mark.parametrize("crop,hp,vp,loc_it,method", [((400, 150, 100, 70), 3, 2, 3, 0), ((100, 60, 91, 66), 2, 2, 2, 0),
+                                                       ((700, 250, 72, 54), 1, 3, 3, 0), ((250, 300, 80, 60), 2, 3, 2, 1)])
+def test_match_growing_with_image_partitions(ctx, oracle, crop, hp, vp, loc_it, method):
     # -split_img 1: iteration 0 on the whole image, then growings on an hp x vp grid of partitions (odd iterations),
     # on its transpose (even ones) and on the grid again for the last growing; remainders and the reference's index
     # adjustment quirk (odd width with two columns) included
     i0, i1 = sintel_pair(crop)
     a, b = oracle.preprocess_local(i0, i1)
     go, ba = _seed_flows(oracle, a, b, 0.015, seed=hp * 10 + vp)
-    want, wene, st = oracle.local_faldoi(a, b, go, ba, loc_it=loc_it, split_img=1, h_parts=hp, v_parts=vp)
-    got, gene, gst = ctx.match_growing(a, b, go, ba, preprocessed=1, loc_it=loc_it, split_img=1, h_parts=hp, v_parts=vp)
+    want, wene, st = oracle.local_faldoi(a, b, go, ba, loc_it=loc_it, split_img=1, h_parts=hp, v_parts=vp, method=method)
+    got, gene, gst = ctx.match_growing(a, b, go, ba, preprocessed=1, loc_it=loc_it, split_img=1, h_parts=hp, v_parts=vp, method=method)
     assert list(gst.solves) == [st[1], st[4]] and list(gst.pops) == [st[0], st[3]] and list(gst.fills) == [st[2], st[5]]
     assert bits_equal(got, want), mismatch_report(got, want)
     assert bits_equal(gene, wene)
-    plain, _, _ = oracle.local_faldoi(a, b, go, ba, loc_it=loc_it)
+    plain, _, _ = oracle.local_faldoi(a, b, go, ba, loc_it=loc_it, method=method)
     assert not bits_equal(plain, want)                     # partitioning changes the result, in the reference too
     sal = np.ones_like(a)
     with pytest.raises(F.FaldoiError):
