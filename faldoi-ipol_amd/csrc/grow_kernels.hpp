@@ -708,6 +708,40 @@ void grow_kernel_dense(const GrowDir *__restrict__ dirs, int mode, int iteration
     grow_body(sm, dirs, mode, iteration, wr, max_iter_patch, budget);
 }
 
+// insert_potential_candidates (src/local_faldoi.cpp:813-846) + prepare_data_for_growing (:860-870) for one growing per
+// workgroup: every pixel with a finite flow is pushed, in row-major order, with its stored energy into the (empty)
+// queue -- N successive push_heap calls, serial by nature, done by the first wavefront with its cooperative
+// sift-up (64 pixels are fetched at a time, then visited in order) -- and the per-pixel state is reset.
+__global__ __launch_bounds__(kPatchThreads) void grow_reseed_kernel(const GrowDir *__restrict__ dirs)
+{
+    const GrowDir D = dirs[blockIdx.x];
+    const int t = threadIdx.x, n = D.nx * D.ny;
+    if (t < 64) {
+        int size = 0;
+        for (int p0 = 0; p0 < n; p0 += 64) {
+            const int p = p0 + t < n ? p0 + t : n - 1;
+            const float u = D.out[p], v = D.out[D.pe + p], e = D.ene[p];
+            const unsigned long long fin = __builtin_amdgcn_ballot_w64(p0 + t < n && __builtin_isfinite(u) && __builtin_isfinite(v));
+            for (unsigned long long rest = fin; rest != 0ull; rest &= rest - 1) {
+                const int q = __builtin_ctzll(rest), g = p0 + q;
+                if (size < D.heap_cap) heap_push_wave(D.heap, size, g % D.nx, g / D.nx, lane_read(u, q), lane_read(v, q), lane_read(e, q));
+                else if (t == 0) D.ctl->overflow = 1;
+            }
+        }
+        if (t == 0) {
+            D.ctl->heap_size = size;
+            D.ctl->done = 0;
+        }
+    }
+    __syncthreads();
+    for (int p = t; p < n; p += kPatchThreads) {
+        D.fixed[p] = 0;
+        D.ene[p] = __builtin_inff();
+        D.out[p] = __builtin_nanf("");
+        D.out[D.pe + p] = __builtin_nanf("");
+    }
+}
+
 // Test hook: replays push (1) / pop (0) operations on the device queue with one wavefront.
 __global__ __launch_bounds__(kPatchThreads) void heap_replay_kernel(Candidate *heap, int nops, const int *__restrict__ ops,
                                                                   const float *__restrict__ sims, int *__restrict__ popped,
