@@ -13,9 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libfaldoi_hip.so")
 SOURCES = [os.path.join(HERE, "csrc", "faldoi_hip.hip")]
-DEPS = SOURCES + [os.path.join(HERE, "csrc", f) for f in ("faldoi_device.hpp", "tvl1_kernels.hpp",
-                                                          "preprocess_kernels.hpp", "nltv_kernels.hpp", "local_kernels.hpp")] + [
-    os.path.join(ROOT, "include", "faldoi_hip.h")]
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))
+              if f.endswith((".hip", ".hpp", ".inc"))) + [os.path.join(ROOT, "include", "faldoi_hip.h")]
 BIN = os.path.join(HERE, "bin")
 HOST = os.path.join(HERE, "host")
 HOST_COMMON = [os.path.join(HOST, "image_io.cpp")]
