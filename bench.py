@@ -205,6 +205,16 @@ def main():
                                    "cores": int(O.lib().orc_num_threads()), "kind": "port",
                                    "sample": "the full step once (1 pair, %d warps x %d iterations, %.1f s)"
                                              % (WARPS, INNER, cpu_s)}
+            # SURVEY 8d also asks for the one-thread figure: a tenth of the schedule (30 warps x 10 iterations)
+            nthreads = int(O.lib().orc_num_threads())
+            O.lib().orc_set_num_threads(1)
+            t1 = time.perf_counter()
+            O.tvl1_global(i0n, i1n, u0, warps=WARPS // 10, max_inner=INNER, tol_stop=False)
+            cpu1_s = time.perf_counter() - t1
+            O.lib().orc_set_num_threads(nthreads)
+            out["cpu_baseline_1thread"] = {"value": round(W * H * (WARPS // 10) * INNER / cpu1_s / 1e6, 1), "unit": "Mpx*iter/s",
+                                           "cores": 1, "kind": "port",
+                                           "sample": "%d warps x %d iterations of the same pair (%.1f s)" % (WARPS // 10, INNER, cpu1_s)}
             out["epe_vs_cpu"] = {"mean_epe_px": epe, "bit_identical": bool(
                 np.array_equal(gu.view(np.uint32), ou.view(np.uint32))), "gate": 1e-4}
         print(json.dumps(out), flush=True)
