@@ -253,6 +253,8 @@ __global__ __launch_bounds__(256, WPS) void tvl1_warp_kernel(float *__restrict__
     const float *I1y = slab + (size_t)P_I1Y * plane_elems;
     const float u1 = st[0 * plane_elems + p];
     const float u2 = st[1 * plane_elems + p];
+    float i0v = I0[p];
+    asm volatile("" : "+v"(i0v));                               // fetched with the flow, not in a round trip of its own at the end
     const float uu = (float)x + u1;                             // src/bicubic_interpolation.c:259-260
     const float vv = (float)y + u2;
     const BicubicTaps tp = bicubic_taps(uu, vv, nx, ny);
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256, WPS) void tvl1_warp_kernel(float *__restrict__
         wx = bicubic_eval(I1x, tp, nx);
         wy = bicubic_eval(I1y, tp, nx);
     }
-    slab[(size_t)P_RC * plane_elems + p] = rho_const(w0, wx, wy, u1, u2, I0[p]);
+    slab[(size_t)P_RC * plane_elems + p] = rho_const(w0, wx, wy, u1, u2, i0v);
     slab[(size_t)P_IWX * plane_elems + p] = wx;
     slab[(size_t)P_IWY * plane_elems + p] = wy;
     // ubar = u (:659-660) is not materialised: the first chunk of a warp takes ubar from u.
