@@ -10,7 +10,7 @@
 //                          scripts_python/auxiliar_faldoi_functions.py:19-30)
 //                    deep: columns 1-4 (cut_deep_list :32-45);  cut: already "x0 y0 x1 y1"
 //               [-local_out local.flo] [-sim_out sim_map]      keep the intermediate results
-//               [-m 0|1] [-wr 5] [-loc_it 3] [-max_pch_it 4] [-fb_thresh 2] [-split_img 0|1] [-h_parts 3] [-v_parts 2]
+//               [-m 0|1] [-wr 5] [-loc_it 3] [-max_pch_it 4] [-fb_thresh 2] [-split_img 0|1|2] [-h_parts 3] [-v_parts 2]
 //               [-w 5] [-verbose 0] [-gpu 0]
 #include <cmath>
 #include <cstdio>
@@ -75,7 +75,7 @@ int main(int argc, char *argv[])
         const int gpu = std::stoi(pick_option(args, "gpu", "0"));
         if (args.size() != 5 || (matcher != "sift" && matcher != "deep" && matcher != "cut")) {
             fprintf(stderr, "usage: %s ims.txt matches_fwd.txt matches_bwd.txt out.flo [-matcher sift|deep|cut] [-local_out f.flo] "
-                            "[-sim_out f] [-m 0|1] [-wr 5] [-loc_it 3] [-max_pch_it 4] [-fb_thresh 2] [-split_img 0|1] [-h_parts 3] [-v_parts 2] "
+                            "[-sim_out f] [-m 0|1] [-wr 5] [-loc_it 3] [-max_pch_it 4] [-fb_thresh 2] [-split_img 0|1|2] [-h_parts 3] [-v_parts 2] "
                             "[-w 5] [-verbose 0] [-gpu 0]\n", argv[0]);
             return 1;
         }

@@ -14,7 +14,8 @@
 // (src/iio.c:3505-3511).  Like the reference, the local step ignores the values of
 // the -p file (src/energy_model.cpp:704-709).
 // Built: -m 0 (TV-l2 coupled) and -m 1 (TV-l2 coupled with weights), with or without image partitions
-// (-split_img 1 -h_parts H -v_parts V; not together with saliency maps).  Other functionals are refused loudly.
+// (-split_img 1 -h_parts H -v_parts V; not together with saliency maps; -split_img 2, additive: partitions from
+// local iteration 0 on -- faster for one pair, deterministic, but not the reference's flow).  Other functionals are refused loudly.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

@@ -363,7 +363,8 @@ void prune_and_reseed(Direction *d, int w, int h, float fb_thresh)       // :123
 
 /* split_img = 0: whole-image growings.  split_img = 1 (-split_img 1 -h_parts H -v_parts V): local iteration 0 on the
  * whole image, odd iterations on an H x V grid of partitions, even ones on a V x H grid, the last growing on the H x V
- * grid (src/local_faldoi.cpp:1284-1700).  stats as before, partitions included. */
+ * grid (src/local_faldoi.cpp:1284-1700).  split_img = 2 (not in the reference): iteration 0 on the V x H grid too.
+ * stats as before, partitions included. */
 extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,
                                        const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
                                        int method, int split_img, int h_parts, int v_parts, float *out_flow, float *ene_val,
@@ -386,7 +387,7 @@ extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const
         for (int q = 0; q < count; q++) local_growing(P[q / ndir].d[q % ndir], it);
     };
     for (int it = 0; it < loc_it; it++) {                                          // :1184-1640
-        if (!split_img || it == 0) {
+        if (!split_img || (it == 0 && split_img != 2)) {
 #pragma omp parallel for num_threads(2)
             for (int k = 0; k < 2; k++) local_growing(d[k], it);
         } else {

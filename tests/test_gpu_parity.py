@@ -806,6 +806,25 @@ def test_match_growing_with_image_partitions(ctx, oracle, crop, hp, vp, loc_it, 
         ctx.match_growing(a, b, go, ba, sal, sal, preprocessed=1, split_img=1)
 
 
+@pytest.mark.parametrize("crop,hp,vp,method", [((400, 150, 100, 70), 3, 2, 0), ((250, 300, 80, 60), 2, 3, 1)])
+def test_match_growing_partitions_from_the_first_iteration(ctx, oracle, crop, hp, vp, method):
+    # -split_img 2 (additive, not in the reference): local iteration 0 runs on the transposed grid as well, so the
+    # 2 * hp * vp growings are in flight from the start; same bits as the CPU restatement of that schedule, and a
+    # result different from both the reference's partition mode and the whole-image run
+    i0, i1 = sintel_pair(crop)
+    a, b = oracle.preprocess_local(i0, i1)
+    go, ba = _seed_flows(oracle, a, b, 0.03, seed=5)
+    want, wene, st = oracle.local_faldoi(a, b, go, ba, split_img=2, h_parts=hp, v_parts=vp, method=method)
+    got, gene, gst = ctx.match_growing(a, b, go, ba, preprocessed=1, split_img=2, h_parts=hp, v_parts=vp, method=method)
+    assert list(gst.solves) == [st[1], st[4]] and list(gst.pops) == [st[0], st[3]] and list(gst.fills) == [st[2], st[5]]
+    assert bits_equal(got, want), mismatch_report(got, want)
+    assert bits_equal(gene, wene)
+    ref_mode, _, _ = oracle.local_faldoi(a, b, go, ba, split_img=1, h_parts=hp, v_parts=vp, method=method)
+    assert not bits_equal(ref_mode, want)
+    with pytest.raises(F.FaldoiError):
+        ctx.match_growing(a, b, go, ba, preprocessed=1, split_img=3)
+
+
 def test_match_growing_partitions_fall_back_to_the_whole_image(ctx, oracle):
     # no backward seed at all: some partition queue never receives a candidate, so every partitioned iteration reverts
     # to whole-image growings (src/local_faldoi.cpp:1349-1370) while the partitions' forward queues pile up unused
