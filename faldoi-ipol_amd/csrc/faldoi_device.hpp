@@ -278,10 +278,12 @@ __device__ __forceinline__ void dual_step(float &xi11, float &xi12, float &xi21,
     // g <= 1  =>  sqrt(g) <= 1 (correctly rounded)  =>  max(1, sqrt(g)) == 1  =>  a / 1 == a.
     // When no lane of the wavefront has g > 1 the square root and the four quotients are skipped
     // as a whole (wave-uniform branch); otherwise every lane takes the general path, which
-    // returns the same bits for the g <= 1 lanes.  (NaN g: both paths leave NaN duals.)
-    if (__builtin_amdgcn_ballot_w64(g > 1.0f) != 0ull) {
+    // returns the same bits for the g <= 1 lanes.  NaN g (a NaN dual: windows over pruned, unfilled flow): the
+    // reference's MAX(1, xi_N) is (1 > xi_N) ? 1 : xi_N, i.e. NaN, and all four duals of the pixel become NaN, not
+    // only the NaN ones -- so the tests are written as "not g <= 1" and a NaN g takes the general path as NaN.
+    if (__builtin_amdgcn_ballot_w64(!(g <= 1.0f)) != 0ull) {
         // max(1, sqrt(g)) == sqrt(max(1, g)): sqrt is monotone and sqrt(1) == 1 exactly
-        const float n = sqrt_ge1((g > 1.0f) ? g : 1.0f);
+        const float n = sqrt_ge1((g <= 1.0f) ? 1.0f : g);
         const double rn = recip_f64(n);             // one reciprocal, four exact quotients
         xi11 = div_by(xi11, n, rn);
         xi12 = div_by(xi12, n, rn);

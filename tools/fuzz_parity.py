@@ -1,0 +1,177 @@
+"""Randomised parity sweep: the HIP path against the CPU checker over many random sizes / parameters.
+
+Wider than tests/ (which pins chosen cases): every case draws its frame size, crop, seeds and parameters from a seeded
+generator, so a failure is reproducible from the printed case number.  Runs on the GPU box:
+    python tools/fuzz_parity.py [--family tvl1,growing,tvcsad,nltv] [--cases 200] [--seed 0] [--minutes 10]"""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import faldoi_ipol_amd as F  # noqa: E402
+import util  # noqa: E402
+from oracle import oracle as O  # noqa: E402  (checker)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--family", default="tvl1,growing,tvcsad,nltv")
+ap.add_argument("--cases", type=int, default=200)
+ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--minutes", type=float, default=10.0)
+ap.add_argument("--override", default="", help="growing family: k=v,... applied over the drawn parameters (with --only)")
+ap.add_argument("--only", type=int, default=-1, help="run this one case and say what differs")
+a = ap.parse_args()
+ctx = F.Context()
+FULL0, FULL1 = util.sintel_pair()
+HARD0 = util.load_rgb_planar(os.path.join(util.GOLDEN, "sintel_final_hard_frame_0002.png"))
+HARD1 = util.load_rgb_planar(os.path.join(util.GOLDEN, "sintel_final_hard_frame_0003.png"))
+
+
+def crop_pair(rng, w, h):
+    a0, a1 = (FULL0, FULL1) if rng.random() < 0.6 else (HARD0, HARD1)
+    x0, y0 = int(rng.integers(0, 1024 - w)), int(rng.integers(0, 436 - h))
+    return (np.ascontiguousarray(a0[:, y0:y0 + h, x0:x0 + w]), np.ascontiguousarray(a1[:, y0:y0 + h, x0:x0 + w])), (x0, y0, w, h)
+
+
+def case_tvl1(rng):
+    w, h = int(rng.integers(3, 230)), int(rng.integers(3, 160))
+    if rng.random() < 0.5:
+        i0n, i1n, _ = util.synthetic_pair(max(w, 4), max(h, 4), seed=int(rng.integers(1 << 30)), amp=float(rng.uniform(0, 6)))
+        i0n, i1n = np.ascontiguousarray(i0n[:h, :w]), np.ascontiguousarray(i1n[:h, :w])
+        desc = "synthetic %dx%d" % (w, h)
+    else:
+        w, h = max(w, 8), max(h, 8)
+        (c0, c1), cr = crop_pair(rng, w, h)
+        i0n, i1n = O.preprocess_global(c0, c1)
+        desc = "crop %s" % (cr,)
+    u0 = (rng.normal(0, float(rng.choice([0, 0.5, 3.0])), (2, h, w))).astype(np.float32)
+    prm = dict(warps=int(rng.integers(1, 5)), max_inner=int(rng.integers(1, 45)), tol_stop=bool(rng.random() < 0.5),
+               lam=float(rng.choice([40.0, 10.0, 0.5, 120.0])), theta=float(rng.choice([0.3, 0.1, 0.8])),
+               tau=float(rng.choice([0.125, 0.25, 0.05])), tol=float(rng.choice([0.01, 0.001, 0.1])))
+    chunk = int(rng.choice([0, 1, 2, 3, 5, 7, 10]))
+    xi = (rng.normal(0, 0.3, (4, h, w))).astype(np.float32) if rng.random() < 0.3 else None
+    desc += " %s chunk=%d xi=%s" % (prm, chunk, xi is not None)
+    want, wit, werr, wxi = O.tvl1_global(i0n, i1n, u0, xi=xi, **prm)
+    g = dict(prm)
+    g["lambda_"] = g.pop("lam")
+    g["tol_stop"] = int(g["tol_stop"])
+    got, git, gerr, gxi, _ = ctx.tvl1_global(i0n, i1n, u0, xi=xi if xi is not None else np.zeros((4, h, w), np.float32), chunk=chunk, **g)
+    ok = util.bits_equal(got, want) and np.array_equal(git, wit) and util.bits_equal(gerr, werr) and util.bits_equal(gxi, wxi)
+    return ok, desc
+
+
+def seed_flows(rng, a, b, frac, noise):
+    out = []
+    for src, dst in ((a, b), (b, a)):
+        u = O.tvl1_global(src, dst, np.zeros((2,) + src.shape, np.float32), warps=2, max_inner=30)[0]
+        s = np.full_like(u, np.nan)
+        m = rng.random(src.shape) < frac
+        s[:, m] = np.round(u[:, m] + rng.normal(0, noise, u[:, m].shape))
+        out.append(s)
+    return out
+
+
+def case_growing(rng):
+    w, h = int(rng.integers(12, 110)), int(rng.integers(12, 80))
+    (c0, c1), cr = crop_pair(rng, w, h)
+    i0n, i1n = O.preprocess_local(c0, c1)
+    go, ba = seed_flows(rng, i0n, i1n, float(rng.choice([0.003, 0.01, 0.03, 0.1])), float(rng.choice([0, 0, 1.5])))
+    prm = dict(wr=int(rng.integers(1, 6)), loc_it=int(rng.integers(0, 4)), max_iter_patch=int(rng.integers(1, 7)),
+               fb_thresh=float(rng.choice([2.0, 0.5, 0.13, 5.0])), method=int(rng.integers(0, 2)))
+    split = {}
+    sal = (None, None)
+    r = rng.random()
+    if r < 0.4 and w >= 40 and h >= 40:
+        split = dict(split_img=int(rng.integers(1, 3)), h_parts=int(rng.integers(1, 4)), v_parts=int(rng.integers(1, 4)))
+    elif r < 0.6:
+        sal = tuple(rng.uniform(0.2, 1.0, (h, w)).astype(np.float32) for _ in range(2))
+    budget = int(rng.choice([16384, 257, 5000]))
+    for kv in a.override.split(","):
+        if kv:
+            k, v = kv.split("=")
+            if k == "budget":
+                budget = int(v)
+            elif k in ("split_img", "h_parts", "v_parts"):
+                split[k] = int(v)
+            else:
+                prm[k] = float(v) if k == "fb_thresh" else int(v)
+    desc = "crop %s %s %s sal=%s seeds=%d/%d budget=%d" % (cr, prm, split, sal[0] is not None, np.isfinite(go[0]).sum(), np.isfinite(ba[0]).sum(), budget)
+    want, wene, st = O.local_faldoi(i0n, i1n, go, ba, sal0=sal[0], sal1=sal[1], **prm, **split)
+    got, gene, gst = ctx.match_growing(i0n, i1n, go, ba, sal[0], sal[1], preprocessed=1, budget=budget, **prm, **split)
+    ok = (util.bits_equal(got, want) and util.bits_equal(gene, wene) and list(gst.solves) == [st[1], st[4]]
+          and list(gst.pops) == [st[0], st[3]] and list(gst.fills) == [st[2], st[5]])
+    if not ok:
+        desc += " | flow: %s | energy: %s | pops/windows/fills device %s checker %s" % (
+            util.mismatch_report(got, want), util.mismatch_report(gene, wene),
+            [list(gst.pops), list(gst.solves), list(gst.fills)], [int(v) for v in st])
+        desc += " | device kept per iteration (fwd, bwd): %s" % [round(v * w * h) for v in gst.fb_kept[:2 * prm["loc_it"]]]
+    return ok, desc
+
+
+def case_tvcsad(rng):
+    w, h = int(rng.integers(10, 120)), int(rng.integers(10, 90))
+    (c0, c1), cr = crop_pair(rng, w, h)
+    i0n, i1n = O.preprocess_global(c0, c1)
+    u0 = (rng.normal(0, float(rng.choice([0, 0.5])), (2, h, w))).astype(np.float32)
+    prm = dict(warps=int(rng.integers(1, 4)), max_inner=int(rng.integers(1, 60)), tol=float(rng.choice([0.01, 0.002, 0.05])),
+               lam=float(rng.choice([0.85, 0.3, 3.0])), theta=0.3, tau=0.125)
+    desc = "crop %s %s" % (cr, prm)
+    want, wit, werr, wxi = O.tvcsad_global(i0n, i1n, u0, **prm)
+    g = dict(prm)
+    g["lambda_"] = g.pop("lam")
+    res = ctx.tvcsad_global(i0n, i1n, u0, **g)
+    got, git = res[0], res[1]
+    return util.bits_equal(got, want) and np.array_equal(git, wit), desc
+
+
+def case_nltv(rng):
+    w, h = int(rng.integers(8, 90)), int(rng.integers(8, 70))
+    (c0, c1), cr = crop_pair(rng, w, h)
+    i0n, i1n = O.preprocess_global(c0, c1)
+    lab = O.image_to_lab(c0)
+    u0 = (rng.normal(0, float(rng.choice([0, 0.5])), (2, h, w))).astype(np.float32)
+    prm = dict(warps=int(rng.integers(1, 3)), max_inner=int(rng.integers(1, 40)))
+    l1 = rng.random() < 0.4
+    desc = "crop %s %s %s" % (cr, prm, "NLTV-L1" if l1 else "NLTV-CSAD")
+    if l1:
+        want = O.nltvl1_global(i0n, i1n, lab, u0, **prm)
+        got = ctx.nltvl1_global(i0n, i1n, lab, u0, **prm)
+    else:
+        want = O.nltvcsad_global(i0n, i1n, lab, u0, **prm)
+        got = ctx.nltvcsad_global(i0n, i1n, lab, u0, **prm)
+    want = want[0] if isinstance(want, tuple) else want
+    got = got[0] if isinstance(got, tuple) else got
+    return util.bits_equal(got, want), desc
+
+
+FAMILIES = {"tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv}
+fams = [f for f in a.family.split(",") if f]
+t_end = time.time() + a.minutes * 60
+bad = 0
+refused = {}
+count = {f: 0 for f in fams}
+for n in (range(a.cases) if a.only < 0 else [a.only]):
+    if time.time() > t_end:
+        break
+    fam = fams[n % len(fams)]
+    rng = np.random.default_rng([a.seed, n])
+    try:
+        ok, desc = FAMILIES[fam](rng)
+    except F.FaldoiError as e:                       # a refused configuration is fine if it says why
+        ok, desc = True, "refused: %s" % e
+        refused[str(e)[:90]] = refused.get(str(e)[:90], 0) + 1
+    except Exception:
+        ok, desc = False, traceback.format_exc()
+    count[fam] += 1
+    if not ok:
+        bad += 1
+        print("MISMATCH case %d (%s, --seed %d): %s" % (n, fam, a.seed, desc), flush=True)
+    elif n % 20 == 0 or a.only >= 0:
+        print("case %d ok (%s): %s" % (n, fam, desc[:150]), flush=True)
+print("done: %s cases, %d mismatches; refused configurations: %s" % (count, bad, refused), flush=True)
+sys.exit(1 if bad else 0)
