@@ -149,7 +149,150 @@ def case_nltv(rng):
     return util.bits_equal(got, want), desc
 
 
-FAMILIES = {"tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv}
+def same_up_to_nan_payload(x, y):
+    x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
+    nx_, ny_ = np.isnan(x), np.isnan(y)
+    return x.shape == y.shape and np.array_equal(nx_, ny_) and np.array_equal(x[~nx_].view(np.uint32), y[~ny_].view(np.uint32))
+
+
+def case_growing_edge(rng):
+    """Seeds the matcher would never give: none at all, everywhere, far outside the frame, fractional, one direction only."""
+    w, h = int(rng.integers(6, 70)), int(rng.integers(6, 50))
+    (c0, c1), cr = crop_pair(rng, w, h)
+    i0n, i1n = O.preprocess_local(c0, c1)
+    kind = int(rng.integers(0, 6))
+    go, ba = np.full((2, h, w), np.nan, np.float32), np.full((2, h, w), np.nan, np.float32)
+    if kind == 1:                                   # every pixel a seed
+        go = rng.integers(-3, 4, (2, h, w)).astype(np.float32)
+        ba = rng.integers(-3, 4, (2, h, w)).astype(np.float32)
+    elif kind == 2:                                 # flows that leave the frame
+        for s in (go, ba):
+            m = rng.random((h, w)) < 0.05
+            s[:, m] = rng.integers(-200, 200, (2, int(m.sum()))).astype(np.float32)
+    elif kind == 3:                                 # fractional seeds, forward only
+        m = rng.random((h, w)) < 0.05
+        go[:, m] = rng.normal(0, 2, (2, int(m.sum()))).astype(np.float32)
+    elif kind == 4:                                 # a single seed per direction
+        go[:, h // 2, w // 2] = 0
+        ba[:, 0, 0] = 1
+    elif kind == 5:                                 # one component finite, the other NaN: not a seed (:770)
+        m = rng.random((h, w)) < 0.05
+        go[0, m] = 1.0
+        ba[:, m] = 0.0
+    prm = dict(wr=int(rng.integers(1, 6)), loc_it=int(rng.integers(0, 4)), max_iter_patch=int(rng.integers(1, 9)),
+               fb_thresh=float(rng.choice([2.0, 0.05, 50.0])), method=int(rng.integers(0, 2)))
+    desc = "crop %s kind %d %s" % (cr, kind, prm)
+    want, wene, st = O.local_faldoi(i0n, i1n, go, ba, **prm)
+    got, gene, gst = ctx.match_growing(i0n, i1n, go, ba, preprocessed=1, **prm)
+    ok = (same_up_to_nan_payload(got, want) and same_up_to_nan_payload(gene, wene) and list(gst.solves) == [st[1], st[4]]
+          and list(gst.pops) == [st[0], st[3]] and list(gst.fills) == [st[2], st[5]])
+    if not ok:
+        desc += " | pops/windows/fills device %s checker %s" % ([list(gst.pops), list(gst.solves), list(gst.fills)], [int(v) for v in st])
+    return ok, desc
+
+
+def case_batch(rng):
+    """Several pairs in one call (RGB frames, device preprocessing), default and register-capped builds."""
+    w, h = int(rng.integers(16, 64)), int(rng.integers(16, 48))
+    k = int(rng.integers(2, 7))
+    i0s, i1s, gos, bas, wants = [], [], [], [], []
+    prm = dict(wr=int(rng.integers(2, 6)), loc_it=int(rng.integers(1, 4)), method=int(rng.integers(0, 2)))
+    for _ in range(k):
+        (c0, c1), _cr = crop_pair(rng, w, h)
+        a_, b_ = O.preprocess_local(c0, c1)
+        go, ba = seed_flows(rng, a_, b_, 0.03, 0)
+        i0s.append(c0); i1s.append(c1); gos.append(go); bas.append(ba)
+        wants.append(O.local_faldoi(a_, b_, go, ba, **prm)[0])
+    dense = rng.random() < 0.5
+    os.environ["FALDOI_GROW_DENSE"] = "1" if dense else "0"
+    outs, _, _ = ctx.match_growing_batch(i0s, i1s, gos, bas, **prm)
+    os.environ["FALDOI_GROW_DENSE"] = "0"
+    return all(util.bits_equal(o, w_) for o, w_ in zip(outs, wants)), "%d pairs %dx%d %s dense=%s" % (k, w, h, prm, dense)
+
+
+def case_prims(rng):
+    """Stencils, warps, preprocessing, resampling and the pruning test on random sizes and values."""
+    w, h = int(rng.integers(2, 150)), int(rng.integers(2, 110))
+    img = rng.uniform(0, 255, (h, w)).astype(np.float32)
+    v1 = rng.normal(0, 1, (h, w)).astype(np.float32)
+    v2 = rng.normal(0, 1, (h, w)).astype(np.float32)
+    L = O.lib()
+    bad = []
+    dx, dy = O.centered_gradient(img)
+    gx, gy = ctx.centered_gradient(img)
+    if not (util.bits_equal(gx, dx) and util.bits_equal(gy, dy)):
+        bad.append("centered_gradient")
+    fx, fy = np.empty_like(img), np.empty_like(img)
+    L.orc_forward_gradient(img, fx, fy, w, h)
+    if not all(util.bits_equal(x, y) for x, y in zip(ctx.forward_gradient(img), (fx, fy))):
+        bad.append("forward_gradient")
+    dv = np.empty_like(img)
+    L.orc_divergence(v1, v2, dv, w, h)
+    if not util.bits_equal(ctx.divergence(v1, v2), dv):
+        bad.append("divergence")
+    scale = float(rng.choice([0.5, 3.0, 40.0, 400.0]))
+    uu = (rng.normal(0, scale, (h, w))).astype(np.float32)
+    vv = (rng.normal(0, scale, (h, w))).astype(np.float32)
+    if rng.random() < 0.3:
+        uu[rng.random((h, w)) < 0.02] = np.nan
+    for bo in (True, False):
+        wo = np.empty_like(img)
+        L.orc_bicubic_warp(img, uu, vv, wo, w, h, int(bo))
+        if not same_up_to_nan_payload(ctx.bicubic_warp(img, uu, vv, bo), wo):
+            bad.append("bicubic_warp border_out=%s" % bo)
+    if w >= 6 and h >= 6:
+        f0 = np.stack([uu, vv]) * np.float32(0.05)
+        f1 = -np.stack([vv, uu]) * np.float32(0.05)
+        eps = float(rng.choice([2.0, 0.3, 0.01]))
+        tr = np.empty((h, w), np.int32)
+        L.orc_fb_consistency_check(f0, f1, tr, w, h, eps)
+        if not np.array_equal(ctx.fb_consistency_check(f0, f1, eps), tr):
+            bad.append("fb_consistency_check")
+    if w >= 8 and h >= 8:
+        pd = int(rng.choice([1, 3]))
+        c0 = rng.uniform(0, 255, (pd, h, w)).astype(np.float32)
+        c1 = rng.uniform(0, 255, (pd, h, w)).astype(np.float32)
+        if not all(util.bits_equal(x, y) for x, y in zip(ctx.preprocess_global(c0, c1), O.preprocess_global(c0, c1))):
+            bad.append("preprocess_global")
+        if not all(util.bits_equal(x, y) for x, y in zip(ctx.preprocess_local(c0, c1), O.preprocess_local(c0, c1))):
+            bad.append("preprocess_local")
+        fac = float(rng.choice([0.5, 0.75, 0.8]))
+        zo = O.zoom_out(img, fac)
+        if not util.bits_equal(ctx.zoom_out(img, fac), zo):
+            bad.append("zoom_out %g" % fac)
+        if not util.bits_equal(ctx.zoom_in(zo, w, h), O.zoom_in(zo, w, h)):
+            bad.append("zoom_in")
+    return not bad, "%dx%d %s" % (w, h, bad)
+
+
+def case_tvl1_nan(rng):
+    """NaN or absurdly large (finite) entries in the initial flow, NaN in a frame: same NaN set, same finite bits.
+    (Infinities and magnitudes near FLT_MAX are outside the range of the exact-quotient sequences)"""
+    w, h = int(rng.integers(8, 120)), int(rng.integers(8, 90))
+    i0n, i1n, gt = util.synthetic_pair(w, h, seed=int(rng.integers(1 << 30)), amp=2.0)
+    u0 = gt.copy()
+    for _ in range(int(rng.integers(1, 4))):
+        u0[int(rng.integers(0, 2)), int(rng.integers(0, h)), int(rng.integers(0, w))] = float(rng.choice([np.nan, np.nan, 1e4, -3e5]))
+    if rng.random() < 0.3:
+        i1n = i1n.copy()
+        i1n[int(rng.integers(0, h)), int(rng.integers(0, w))] = np.nan
+    prm = dict(warps=int(rng.integers(1, 4)), max_inner=int(rng.integers(1, 25)), tol_stop=bool(rng.random() < 0.5))
+    chunk = int(rng.choice([0, 1, 4, 10]))
+    want, wit, _, _ = O.tvl1_global(i0n, i1n, u0, **prm)
+    got, git, _, _, _ = ctx.tvl1_global(i0n, i1n, u0, warps=prm["warps"], max_inner=prm["max_inner"], tol_stop=int(prm["tol_stop"]), chunk=chunk)
+    ok = same_up_to_nan_payload(got, want) and np.array_equal(git, wit)
+    desc = "%dx%d %s chunk=%d nan=%d" % (w, h, prm, chunk, np.isnan(want).sum())
+    if not ok:
+        bad = np.argwhere((np.isnan(got) != np.isnan(want)) | (~np.isnan(want) & (got.view(np.uint32) != want.view(np.uint32))))
+        desc += " | injected %s | iters %s vs %s | NaN device %d | %d entries differ, first %s: device %r checker %r" % (
+            [(tuple(ix), float(u0[tuple(ix)])) for ix in np.argwhere(~np.isfinite(u0) | (np.abs(u0) > 1e20))], list(git), list(wit),
+            np.isnan(got).sum(), len(bad), bad[0] if len(bad) else None,
+            float(got[tuple(bad[0])]) if len(bad) else None, float(want[tuple(bad[0])]) if len(bad) else None)
+    return ok, desc
+
+
+FAMILIES = {"tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv,
+            "growing_edge": case_growing_edge, "batch": case_batch, "prims": case_prims, "tvl1_nan": case_tvl1_nan}
 fams = [f for f in a.family.split(",") if f]
 t_end = time.time() + a.minutes * 60
 bad = 0
