@@ -291,7 +291,63 @@ def case_tvl1_nan(rng):
     return ok, desc
 
 
-FAMILIES = {"tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv,
+def case_tvl1_batch(rng):
+    """Several pairs of one size resident at once: every pair stops on its own (device-side loop control), the batch
+    is solved twice (each solve restarts from the uploaded state), FALDOI_TILE picks the tile shape."""
+    w, h = int(rng.integers(8, 260)), int(rng.integers(8, 180))
+    k = int(rng.integers(2, 7))
+    prm = dict(warps=int(rng.integers(1, 5)), max_inner=int(rng.integers(1, 60)), tol_stop=bool(rng.random() < 0.7),
+               tol=float(rng.choice([0.01, 0.05, 0.002])))
+    chunk = int(rng.choice([0, 1, 3, 5, 10]))
+    tile = str(rng.choice(["", "4,16", "3,12", "4,12", "3,16", "4,8", "3,8", "2,16", "8,8"]))
+    if tile:
+        os.environ["FALDOI_TILE"] = tile
+    else:
+        os.environ.pop("FALDOI_TILE", None)
+    batch = F.Tvl1Batch(ctx, k, w, h)
+    ok, frames, state, notes = True, [], [], []
+    try:
+        for i in range(k):
+            i0n, i1n, gt = util.synthetic_pair(w, h, seed=int(rng.integers(1 << 30)), amp=float(rng.uniform(0, 5)))
+            u0 = (gt * np.float32(rng.choice([0.0, 1.0])) + rng.normal(0, 0.2, gt.shape)).astype(np.float32)
+            batch.upload(i, i0n, i1n, u0)
+            frames.append((i0n, i1n))
+            state.append((u0, None))
+        for rep in range(2):                           # every solve starts from the uploaded state (include/faldoi_hip.h)
+            iters, errs, _, _ = batch.solve(warps=prm["warps"], max_inner=prm["max_inner"], tol_stop=int(prm["tol_stop"]),
+                                           tol=prm["tol"], chunk=chunk)
+            for i in range(k):
+                want, wit, werr, wxi = O.tvl1_global(frames[i][0], frames[i][1], state[i][0], xi=state[i][1], **prm)
+                got, gxi = batch.download(i, want_xi=True)
+                parts = (util.bits_equal(got, want), np.array_equal(iters[i], wit), util.bits_equal(errs[i], werr), util.bits_equal(gxi, wxi))
+                if not all(parts):
+                    ok = False
+                    notes.append("solve %d pair %d flow/iters/err/duals %s iters %s vs %s" % (rep, i, parts, list(iters[i]), list(wit)))
+    finally:
+        batch.close()
+        os.environ.pop("FALDOI_TILE", None)
+    return ok, "%d pairs %dx%d %s chunk=%d tile=%s %s" % (k, w, h, prm, chunk, tile or "auto", notes[:3])
+
+
+def case_growing_big(rng):
+    """Larger frames: deep queues, many relaunches, weighted functional, partitions."""
+    w, h = int(rng.integers(120, 320)), int(rng.integers(90, 220))
+    (c0, c1), cr = crop_pair(rng, w, h)
+    i0n, i1n = O.preprocess_local(c0, c1)
+    go, ba = seed_flows(rng, i0n, i1n, float(rng.choice([0.002, 0.01])), 0)
+    prm = dict(wr=int(rng.integers(3, 6)), loc_it=int(rng.integers(1, 4)), method=int(rng.integers(0, 2)))
+    split = {}
+    if rng.random() < 0.5:
+        split = dict(split_img=int(rng.integers(1, 3)), h_parts=int(rng.integers(2, 6)), v_parts=int(rng.integers(2, 5)))
+    budget = int(rng.choice([16384, 1000, 40000]))
+    want, wene, st = O.local_faldoi(i0n, i1n, go, ba, **prm, **split)
+    got, gene, gst = ctx.match_growing(i0n, i1n, go, ba, preprocessed=1, budget=budget, **prm, **split)
+    ok = (util.bits_equal(got, want) and util.bits_equal(gene, wene) and list(gst.solves) == [st[1], st[4]]
+          and list(gst.pops) == [st[0], st[3]] and list(gst.fills) == [st[2], st[5]])
+    return ok, "crop %s %s %s budget=%d windows=%d" % (cr, prm, split, budget, st[1] + st[4])
+
+
+FAMILIES = {"tvl1_batch": case_tvl1_batch, "growing_big": case_growing_big, "tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv,
             "growing_edge": case_growing_edge, "batch": case_batch, "prims": case_prims, "tvl1_nan": case_tvl1_nan}
 fams = [f for f in a.family.split(",") if f]
 t_end = time.time() + a.minutes * 60
