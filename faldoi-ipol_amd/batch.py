@@ -1,13 +1,13 @@
 """Batch mode: many independent image pairs sharded over the GPUs of one node (BASELINE configs[3]).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-        faldoi-ipol_amd/batch.py jobs.txt [-w 5] [-max_inner 400] [-tol_stop 1]
+        faldoi-ipol_amd/batch.py jobs.txt [-w 5] [-max_inner 400] [-tol_stop 1] [-split_img 0|1|2] [-h_parts 3] [-v_parts 2]
 
 jobs.txt: one job per line, all of one form and one image size:
   `I0.png I1.png in_flow.flo|zero out.flo`   what one `global_faldoi` call takes (2-line list-file semantics);
   `I0.png I1.png s0.flo s1.flo out.flo`      the whole chain of the driver scripts from the sparse seed flows:
-                                             `local_faldoi` (-m 0, all the growings of a shard in one batch) then
-                                             `global_faldoi` on its result.
+                                             `local_faldoi` (-m 0, all the growings of a shard in one batch, on image
+                                             partitions with -split_img) then `global_faldoi` on its result.
 
 Data path: rank 0 decodes the inputs and SCATTERS them over RCCL
 (uint8 frames + fp32 initial flows, one message per rank), every rank prepares and solves its
@@ -87,7 +87,7 @@ def gather_flows(dist, torch, device, rank, world, flows_mine, shape):
     return res
 
 
-def solve_shard_gpu(frames, flows, local_rank, **params):
+def solve_shard_gpu(frames, flows, local_rank, local_params=None, **params):
     """frames (n,2,3,h,w) uint8, flows (n,2,h,w) -> refined flows (n,2,h,w) + per-pair iteration counts."""
     import faldoi_ipol_amd as F
     n = len(frames)
@@ -98,7 +98,8 @@ def solve_shard_gpu(frames, flows, local_rank, **params):
     if flows.shape[1] == 4:                 # pipeline jobs: the local step first, every growing of the shard at once
         i0s = [frames[i, 0].astype(np.float32) for i in range(n)]
         i1s = [frames[i, 1].astype(np.float32) for i in range(n)]
-        local, _, _ = ctx.match_growing_batch(i0s, i1s, [flows[i, :2] for i in range(n)], [flows[i, 2:] for i in range(n)])
+        local, _, _ = ctx.match_growing_batch(i0s, i1s, [flows[i, :2] for i in range(n)], [flows[i, 2:] for i in range(n)],
+                                              **(local_params or {}))
         flows = np.stack(local)
     b = F.Tvl1Batch(ctx, n, w, h)
     for i in range(n):
@@ -126,6 +127,7 @@ def main(argv=None):
         return default
 
     params = dict(warps=int(opt("w", 5)), max_inner=int(opt("max_inner", 400)), tol_stop=int(opt("tol_stop", 1)))
+    local_params = dict(split_img=int(opt("split_img", 0)), h_parts=int(opt("h_parts", 3)), v_parts=int(opt("v_parts", 2)))
     if len(argv) != 1:
         raise SystemExit(__doc__)
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +156,7 @@ def main(argv=None):
     dist.broadcast_object_list(meta, src=0)                     # the job table
     njobs, h, w, outs, planes = meta[0]
     my_fr, my_fl = scatter_inputs(dist, torch, device, rank, world, frames, flows, (njobs, h, w, planes))
-    res, iters = solve_shard_gpu(my_fr, my_fl, local_rank, **params)
+    res, iters = solve_shard_gpu(my_fr, my_fl, local_rank, local_params=local_params, **params)
     allres = gather_flows(dist, torch, device, rank, world, res, (njobs, h, w))
     if rank == 0:
         for j, path in enumerate(outs):

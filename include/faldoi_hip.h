@@ -248,7 +248,8 @@ typedef struct faldoi_local_params {
     int budget;           /* windows per growing per kernel launch (host relaunches until the queue is empty) */
     int verbose;
     int method;           /* -m: 0 = TV-l2 coupled (M_TVL1), 1 = TV-l2 coupled with weights (M_TVL1_W, src/tvl2w_model.cpp) */
-    int split_img;        /* -split_img: 1 = grow on image partitions from local iteration 1 on (src/aux_partitions.cpp); one pair per call.
+    int split_img;        /* -split_img: 1 = grow on image partitions from local iteration 1 on (src/aux_partitions.cpp; every pair of a
+                           * batch on its own partitions, all of them in one launch).
                            * 2 (additive, not in the reference) = from iteration 0 on: 2*H*V growings in flight all the way */
     int h_parts;          /* -h_parts, HOR_PARTS 3 (src/parameters.h:69) */
     int v_parts;          /* -v_parts, VER_PARTS 2 (:70) */

@@ -859,6 +859,28 @@ def test_match_growing_partitions_from_the_first_iteration(ctx, oracle, crop, hp
         ctx.match_growing(a, b, go, ba, preprocessed=1, split_img=3)
 
 
+def test_match_growing_batch_with_partitions(ctx, oracle):
+    # several pairs in one call, each on its own partitions, all growings in one launch; pair 1 has no backward seed,
+    # so it alone falls back to whole-image growings while the others stay partitioned
+    crops = [(400, 150, 90, 60), (100, 60, 90, 60), (700, 250, 90, 60)]
+    i0s, i1s, gos, bas, wants = [], [], [], [], []
+    for q, crop in enumerate(crops):
+        i0, i1 = sintel_pair(crop)
+        a, b = oracle.preprocess_local(i0, i1)
+        go, ba = _seed_flows(oracle, a, b, 0.02, seed=30 + q)
+        if q == 1:
+            ba = np.full_like(ba, np.nan)
+        i0s.append(a); i1s.append(b); gos.append(go); bas.append(ba)
+        wants.append(oracle.local_faldoi(a, b, go, ba, split_img=1, h_parts=3, v_parts=2))
+    outs, enes, gst = ctx.match_growing_batch(i0s, i1s, gos, bas, preprocessed=1, split_img=1, h_parts=3, v_parts=2)
+    for out, ene, (want, wene, st) in zip(outs, enes, wants):
+        assert bits_equal(out, want), mismatch_report(out, want)
+        assert bits_equal(ene, wene)
+    assert list(gst.solves) == [sum(int(w[2][1]) for w in wants), sum(int(w[2][4]) for w in wants)]
+    plain, _, _ = oracle.local_faldoi(i0s[1], i1s[1], gos[1], bas[1])
+    assert bits_equal(plain, wants[1][0])                  # the fall-back pair is the unpartitioned run
+
+
 def test_match_growing_partitions_fall_back_to_the_whole_image(ctx, oracle):
     # no backward seed at all: some partition queue never receives a candidate, so every partitioned iteration reverts
     # to whole-image growings (src/local_faldoi.cpp:1349-1370) while the partitions' forward queues pile up unused

@@ -210,6 +210,28 @@ def case_batch(rng):
     return all(util.bits_equal(o, w_) for o, w_ in zip(outs, wants)), "%d pairs %dx%d %s dense=%s" % (k, w, h, prm, dense)
 
 
+def case_batch_split(rng):
+    """Several pairs, each on its own image partitions; some pairs fall back to the whole image (no backward seed)."""
+    w, h = int(rng.integers(40, 100)), int(rng.integers(40, 80))
+    k = int(rng.integers(2, 6))
+    prm = dict(wr=int(rng.integers(2, 6)), loc_it=int(rng.integers(1, 4)), method=int(rng.integers(0, 2)),
+               fb_thresh=float(rng.choice([2.0, 0.3])))
+    split = dict(split_img=int(rng.integers(1, 3)), h_parts=int(rng.integers(1, 4)), v_parts=int(rng.integers(1, 4)))
+    i0s, i1s, gos, bas, wants = [], [], [], [], []
+    for q in range(k):
+        (c0, c1), _cr = crop_pair(rng, w, h)
+        a_, b_ = O.preprocess_local(c0, c1)
+        go, ba = seed_flows(rng, a_, b_, float(rng.choice([0.01, 0.04])), 0)
+        if rng.random() < 0.25:
+            ba = np.full_like(ba, np.nan)          # this pair's partitions never all get a candidate: whole-image fall-back
+        i0s.append(a_); i1s.append(b_); gos.append(go); bas.append(ba)
+        wants.append(O.local_faldoi(a_, b_, go, ba, **prm, **split))
+    outs, enes, gst = ctx.match_growing_batch(i0s, i1s, gos, bas, preprocessed=1, **prm, **split)
+    ok = all(util.bits_equal(o, w_[0]) and util.bits_equal(e, w_[1]) for o, e, w_ in zip(outs, enes, wants))
+    ok = ok and list(gst.solves) == [sum(int(w_[2][1]) for w_ in wants), sum(int(w_[2][4]) for w_ in wants)]
+    return ok, "%d pairs %dx%d %s %s" % (k, w, h, prm, split)
+
+
 def case_prims(rng):
     """Stencils, warps, preprocessing, resampling and the pruning test on random sizes and values."""
     w, h = int(rng.integers(2, 150)), int(rng.integers(2, 110))
@@ -348,7 +370,7 @@ def case_growing_big(rng):
 
 
 FAMILIES = {"tvl1_batch": case_tvl1_batch, "growing_big": case_growing_big, "tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv,
-            "growing_edge": case_growing_edge, "batch": case_batch, "prims": case_prims, "tvl1_nan": case_tvl1_nan}
+            "growing_edge": case_growing_edge, "batch": case_batch, "batch_split": case_batch_split, "prims": case_prims, "tvl1_nan": case_tvl1_nan}
 fams = [f for f in a.family.split(",") if f]
 t_end = time.time() + a.minutes * 60
 bad = 0

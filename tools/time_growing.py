@@ -20,7 +20,7 @@ ap.add_argument("--pairs", type=int, default=1)
 ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--budget", type=int, default=16384)
 ap.add_argument("--loc_it", type=int, default=3)
-ap.add_argument("--split", default="", help="H,V: image partitions (-split_img 1 -h_parts H -v_parts V)")
+ap.add_argument("--split", default="", help="H,V[,mode]: image partitions (-split_img mode -h_parts H -v_parts V; mode 1 or 2)")
 ap.add_argument("--hard", action="store_true", help="the final/hard example pair (large motion) instead of clean/easy")
 a = ap.parse_args()
 crop = tuple(int(v) for v in a.crop.split(",")) if a.crop else None
@@ -42,12 +42,13 @@ for src, dst in ((i0n, i1n), (i1n, i0n)):
 go, ba = seeds
 print("size %dx%d, seeds %d / %d" % (w, h, np.isfinite(go[0]).sum(), np.isfinite(ba[0]).sum()), flush=True)
 t = time.time()
-split = dict(split_img=1, h_parts=int(a.split.split(",")[0]), v_parts=int(a.split.split(",")[1])) if a.split else {}
+sp = [int(v) for v in a.split.split(",")] if a.split else []
+split = dict(split_img=sp[2] if len(sp) > 2 else 1, h_parts=sp[0], v_parts=sp[1]) if sp else {}
 if a.pairs == 1:
     out, ene, st = ctx.match_growing(i0, i1, go, ba, budget=a.budget, iterations_of=a.loc_it, **split)
 else:
     outs, enes, st = ctx.match_growing_batch([i0] * a.pairs, [i1] * a.pairs, [go] * a.pairs, [ba] * a.pairs,
-                                            budget=a.budget, iterations_of=a.loc_it)
+                                            budget=a.budget, iterations_of=a.loc_it, **split)
     out = outs[0]
     assert all(util.bits_equal(o, out) for o in outs)
 dt = time.time() - t
