@@ -192,6 +192,23 @@ def main():
                 grow["cpu_sample"] = "pair 0 once, forward and backward on 2 threads (%.1f s)" % cpu_s
                 grow["bit_identical_pair0"] = bool(np.array_equal(g_out[0].view(np.uint32), want.view(np.uint32)))
             out.setdefault("secondary", {})["local_match_growing"] = grow
+            # one full-size pair: a single growing is sequential, so one pair only gets fast on image partitions
+            # (-split_img 2, additive: partitions from the first local iteration on)
+            a, b = ctx.preprocess_local(full0, full1)
+            sd = []
+            for src, dst in ((a, b), (b, a)):
+                dense = ctx.tvl1_global(src, dst, np.zeros((2, H, W), np.float32), warps=5)[0]
+                sp = np.full_like(dense, np.nan)
+                m = rng.random((H, W)) < 0.011
+                sp[:, m] = np.round(dense[:, m])
+                sd.append(sp)
+            _, _, st1 = ctx.match_growing(full0, full1, sd[0], sd[1], split_img=2, h_parts=8, v_parts=6)
+            out["secondary"]["local_match_growing_one_pair"] = {
+                "size": "%dx%d" % (W, H), "mode": "-split_img 2 -h_parts 8 -v_parts 6 (96 growings in flight)",
+                "windows": int(sum(st1.solves)), "device_ms": round(st1.growing_ms, 1),
+                "windows_per_s": round(sum(st1.solves) / (st1.growing_ms * 1e-3), 0),
+                "note": "whole-image growings (the reference's default): 34 s for the same pair; its own -split_img 1 "
+                        "with 3x2 partitions: 16 s (tools/split_study.py)"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O            # checker + timed CPU baseline only
             i0n, i1n, u0 = pairs[0]
