@@ -21,6 +21,7 @@ ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--budget", type=int, default=16384)
 ap.add_argument("--loc_it", type=int, default=3)
 ap.add_argument("--split", default="", help="H,V[,mode]: image partitions (-split_img mode -h_parts H -v_parts V; mode 1 or 2)")
+ap.add_argument("--verbose", type=int, default=0)
 ap.add_argument("--hard", action="store_true", help="the final/hard example pair (large motion) instead of clean/easy")
 a = ap.parse_args()
 crop = tuple(int(v) for v in a.crop.split(",")) if a.crop else None
@@ -45,10 +46,10 @@ t = time.time()
 sp = [int(v) for v in a.split.split(",")] if a.split else []
 split = dict(split_img=sp[2] if len(sp) > 2 else 1, h_parts=sp[0], v_parts=sp[1]) if sp else {}
 if a.pairs == 1:
-    out, ene, st = ctx.match_growing(i0, i1, go, ba, budget=a.budget, iterations_of=a.loc_it, **split)
+    out, ene, st = ctx.match_growing(i0, i1, go, ba, budget=a.budget, iterations_of=a.loc_it, verbose=a.verbose, **split)
 else:
     outs, enes, st = ctx.match_growing_batch([i0] * a.pairs, [i1] * a.pairs, [go] * a.pairs, [ba] * a.pairs,
-                                            budget=a.budget, iterations_of=a.loc_it, **split)
+                                            budget=a.budget, iterations_of=a.loc_it, verbose=a.verbose, **split)
     out = outs[0]
     assert all(util.bits_equal(o, out) for o in outs)
 dt = time.time() - t
