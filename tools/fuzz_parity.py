@@ -205,8 +205,10 @@ def case_batch(rng):
         wants.append(O.local_faldoi(a_, b_, go, ba, **prm)[0])
     dense = rng.random() < 0.5
     os.environ["FALDOI_GROW_DENSE"] = "1" if dense else "0"
+    os.environ["FALDOI_RESEED"] = "device" if rng.random() < 0.5 else "host"
     outs, _, _ = ctx.match_growing_batch(i0s, i1s, gos, bas, **prm)
     os.environ["FALDOI_GROW_DENSE"] = "0"
+    os.environ.pop("FALDOI_RESEED")
     return all(util.bits_equal(o, w_) for o, w_ in zip(outs, wants)), "%d pairs %dx%d %s dense=%s" % (k, w, h, prm, dense)
 
 
