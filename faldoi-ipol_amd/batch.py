@@ -127,7 +127,8 @@ def main(argv=None):
         return default
 
     params = dict(warps=int(opt("w", 5)), max_inner=int(opt("max_inner", 400)), tol_stop=int(opt("tol_stop", 1)))
-    local_params = dict(split_img=int(opt("split_img", 0)), h_parts=int(opt("h_parts", 3)), v_parts=int(opt("v_parts", 2)))
+    local_params = dict(split_img=int(opt("split_img", 0)), h_parts=int(opt("h_parts", 3)), v_parts=int(opt("v_parts", 2)),
+                        first_h_parts=int(opt("first_h_parts", 0)), first_v_parts=int(opt("first_v_parts", 0)))
     if len(argv) != 1:
         raise SystemExit(__doc__)
     rank = int(os.environ.get("RANK", "0"))

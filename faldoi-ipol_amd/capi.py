@@ -57,7 +57,8 @@ class Tvl1Stats(C.Structure):
 class LocalParams(C.Structure):
     _fields_ = [("w_radio", C.c_int), ("iterations_of", C.c_int), ("max_iter_patch", C.c_int), ("epsilon", C.c_float),
                 ("preprocessed", C.c_int), ("budget", C.c_int), ("verbose", C.c_int), ("method", C.c_int),
-                ("split_img", C.c_int), ("h_parts", C.c_int), ("v_parts", C.c_int)]
+                ("split_img", C.c_int), ("h_parts", C.c_int), ("v_parts", C.c_int),
+                ("first_h_parts", C.c_int), ("first_v_parts", C.c_int)]
 
 
 class LocalStats(C.Structure):

@@ -69,6 +69,8 @@ int main(int argc, char *argv[])
         const int split_img = std::stoi(pick_option(args, "split_img", "0"));
         const int h_parts = std::stoi(pick_option(args, "h_parts", "3"));
         const int v_parts = std::stoi(pick_option(args, "v_parts", "2"));
+        const int first_h_parts = std::stoi(pick_option(args, "first_h_parts", "0"));     // additive, with -split_img 2
+        const int first_v_parts = std::stoi(pick_option(args, "first_v_parts", "0"));
         const int local_method = std::stoi(pick_option(args, "m", "0"));       // 0 / 1: local functional; the global step uses TV-l2 either way (:2132)
         const int warps = std::stoi(pick_option(args, "w", std::to_string(FALDOI_DEFAULT_WARPS_GLOBAL)));
         const int verbose = std::stoi(pick_option(args, "verbose", "0"));
@@ -111,7 +113,7 @@ int main(int argc, char *argv[])
         faldoi_local_params lp;
         faldoi_local_default_params(&lp);
         lp.w_radio = w_radio; lp.iterations_of = loc_it; lp.max_iter_patch = max_pch_it; lp.epsilon = fb_thresh; lp.verbose = verbose;
-        lp.split_img = split_img; lp.h_parts = h_parts; lp.v_parts = v_parts; lp.method = local_method;
+        lp.split_img = split_img; lp.h_parts = h_parts; lp.v_parts = v_parts; lp.first_h_parts = first_h_parts; lp.first_v_parts = first_v_parts; lp.method = local_method;
         std::vector<float> u(2 * n), ene(n);
         faldoi_local_stats ls;
         if (faldoi_match_growing_variational(ctx, go.data(), ba.data(), i0.data.data(), i1.data.data(), nullptr, nullptr, w, h, pd,

@@ -66,6 +66,8 @@ int main(int argc, char *argv[])
         const int split_img = std::stoi(pick_option(args, "split_img", "0"));
         const int h_parts = std::stoi(pick_option(args, "h_parts", "3"));
         const int v_parts = std::stoi(pick_option(args, "v_parts", "2"));
+        const int first_h_parts = std::stoi(pick_option(args, "first_h_parts", "0"));     // additive, with -split_img 2
+        const int first_v_parts = std::stoi(pick_option(args, "first_v_parts", "0"));
         const float fb_thresh = std::stof(pick_option(args, "fb_thresh", "2"));
         const int partial_res = std::stoi(pick_option(args, "partial_res", "0"));
         const int verbose = std::stoi(pick_option(args, "verbose", "0"));
@@ -130,6 +132,7 @@ int main(int argc, char *argv[])
         faldoi_local_default_params(&prm);
         prm.w_radio = w_radio; prm.iterations_of = loc_it; prm.max_iter_patch = max_pch_it; prm.epsilon = fb_thresh;
         prm.verbose = verbose; prm.method = method; prm.split_img = split_img; prm.h_parts = h_parts; prm.v_parts = v_parts;
+        prm.first_h_parts = first_h_parts; prm.first_v_parts = first_v_parts;
         if (budget > 0) prm.budget = budget;
         faldoi_ctx *ctx = nullptr;
         if (faldoi_ctx_create(gpu, &ctx)) { fprintf(stderr, "ERROR: no usable GPU: %s\n", faldoi_last_error()); return 3; }

@@ -253,6 +253,8 @@ typedef struct faldoi_local_params {
                            * 2 (additive, not in the reference) = from iteration 0 on: 2*H*V growings in flight all the way */
     int h_parts;          /* -h_parts, HOR_PARTS 3 (src/parameters.h:69) */
     int v_parts;          /* -v_parts, VER_PARTS 2 (:70) */
+    int first_h_parts;    /* split_img 2 only (additive): grid of local iteration 0, first_h_parts x first_v_parts; */
+    int first_v_parts;    /* 0 = the transposed grid, like every even iteration.  A coarse first grid keeps most of the accuracy */
 } faldoi_local_params;
 typedef struct faldoi_local_stats {
     long long pops[2];    /* candidates popped, forward / backward (summed over the batch) */

@@ -363,11 +363,13 @@ void prune_and_reseed(Direction *d, int w, int h, float fb_thresh)       // :123
 
 /* split_img = 0: whole-image growings.  split_img = 1 (-split_img 1 -h_parts H -v_parts V): local iteration 0 on the
  * whole image, odd iterations on an H x V grid of partitions, even ones on a V x H grid, the last growing on the H x V
- * grid (src/local_faldoi.cpp:1284-1700).  split_img = 2 (not in the reference): iteration 0 on the V x H grid too.
+ * grid (src/local_faldoi.cpp:1284-1700).  split_img = 2 (not in the reference): iteration 0 on the V x H grid too, or on
+ * a first_h_parts x first_v_parts grid of its own when those are > 0.
  * stats as before, partitions included. */
 extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,
                                        const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
-                                       int method, int split_img, int h_parts, int v_parts, float *out_flow, float *ene_val,
+                                       int method, int split_img, int h_parts, int v_parts, int first_h_parts,
+                                       int first_v_parts, float *out_flow, float *ene_val,
                                        long *stats)
 {
     const size_t n = (size_t)w * h;
@@ -376,10 +378,11 @@ extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const
     init_direction(d[1], i1n, i0n, sal1, w, h, wr, max_iter_patch, method);
 #pragma omp parallel for num_threads(2)
     for (int k = 0; k < 2; k++) insert_initial_seeds(d[k], k == 0 ? go : ba);     // :1130-1139
-    std::vector<Partition> PA, PB;
+    std::vector<Partition> PA, PB, PC;
     if (split_img) {                                                               // :1160-1172
         make_partitions(PA, h_parts, v_parts, d);
         make_partitions(PB, v_parts, h_parts, d);
+        if (split_img == 2 && first_h_parts > 0) make_partitions(PC, first_h_parts, first_v_parts, d);   // not in the reference
     }
     auto grow_partitions = [&](std::vector<Partition> &P, int it, int ndir) {
         const int count = (int)P.size() * ndir;
@@ -391,7 +394,7 @@ extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const
 #pragma omp parallel for num_threads(2)
             for (int k = 0; k < 2; k++) local_growing(d[k], it);
         } else {
-            std::vector<Partition> &P = (it % 2 != 0) ? PA : PB;
+            std::vector<Partition> &P = (it == 0 && !PC.empty()) ? PC : (it % 2 != 0) ? PA : PB;
             image_to_partitions(P, d, true);
             if (!any_empty_queues(P)) {
                 grow_partitions(P, it, 2);
@@ -418,7 +421,7 @@ extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const
     memcpy(ene_val, d[0].ene.data(), sizeof(float) * n);
     if (stats) {
         for (int k = 0; k < 2; k++) { stats[3 * k] = d[k].pops; stats[3 * k + 1] = d[k].solves; stats[3 * k + 2] = d[k].fills; }
-        for (std::vector<Partition> *P : { &PA, &PB })
+        for (std::vector<Partition> *P : { &PA, &PB, &PC })
             for (Partition &p : *P)
                 for (int k = 0; k < 2; k++) { stats[3 * k] += p.d[k].pops; stats[3 * k + 1] += p.d[k].solves; stats[3 * k + 2] += p.d[k].fills; }
     }
@@ -428,7 +431,7 @@ extern "C" void orc_local_faldoi(const float *i0n, const float *i1n, const float
                                  const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
                                  int method, float *out_flow, float *ene_val, long *stats)
 {
-    orc_local_faldoi_split(i0n, i1n, go, ba, sal0, sal1, w, h, wr, loc_it, max_iter_patch, fb_thresh, method, 0, 1, 1, out_flow,
+    orc_local_faldoi_split(i0n, i1n, go, ba, sal0, sal1, w, h, wr, loc_it, max_iter_patch, fb_thresh, method, 0, 1, 1, 0, 0, out_flow,
                            ene_val, stats);
 }
 

@@ -106,7 +106,7 @@ def lib():
         L.orc_local_tvl1w_estimate.restype = C.c_float
         L.orc_local_faldoi.argtypes = [_F, _F, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float, C.c_int, _F, _F,
                                        np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
-        L.orc_local_faldoi_split.argtypes = [_F, _F, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float] + [C.c_int] * 4 + [
+        L.orc_local_faldoi_split.argtypes = [_F, _F, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float] + [C.c_int] * 6 + [
             _F, _F, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
         L.orc_fb_consistency_check.argtypes = [_F, _F, _I, C.c_int, C.c_int, C.c_float]
         L.orc_fb_consistency_check.restype = C.c_double
@@ -284,7 +284,7 @@ def preprocess_local(i0, i1):
 
 
 def local_faldoi(i0n, i1n, go, ba, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2.0, sal0=None, sal1=None, method=0,
-                 split_img=0, h_parts=3, v_parts=2):
+                 split_img=0, h_parts=3, v_parts=2, first_h_parts=0, first_v_parts=0):
     """match_growing_variational (-m 0, no partitions).  go/ba: (2,h,w) seed flows, NaN = no seed.
     Returns (out_flow (2,h,w), ene_val (h,w), stats[6])."""
     i0n, i1n, go, ba = f32(i0n), f32(i1n), f32(go), f32(ba)
@@ -293,7 +293,7 @@ def local_faldoi(i0n, i1n, go, ba, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2
     keep = [f32(s) if s is not None else None for s in (sal0, sal1)]
     ptr = [k.ctypes.data if k is not None else None for k in keep]
     lib().orc_local_faldoi_split(i0n, i1n, go, ba, ptr[0], ptr[1], w, h, wr, loc_it, max_iter_patch, fb_thresh, method,
-                                 split_img, h_parts, v_parts, out, ene, st)
+                                 split_img, h_parts, v_parts, first_h_parts, first_v_parts, out, ene, st)
     return out, ene, st
 
 

@@ -857,6 +857,14 @@ def test_match_growing_partitions_from_the_first_iteration(ctx, oracle, crop, hp
     assert bits_equal(gene, wene)
     ref_mode, _, _ = oracle.local_faldoi(a, b, go, ba, split_img=1, h_parts=hp, v_parts=vp, method=method)
     assert not bits_equal(ref_mode, want)
+    # a grid of its own for iteration 0 (coarser: keeps most of the accuracy)
+    first = dict(split_img=2, h_parts=hp, v_parts=vp, first_h_parts=2, first_v_parts=1, method=method)
+    want1, wene1, st1 = oracle.local_faldoi(a, b, go, ba, **first)
+    got1, gene1, gst1 = ctx.match_growing(a, b, go, ba, preprocessed=1, **first)
+    assert bits_equal(got1, want1) and bits_equal(gene1, wene1) and list(gst1.pops) == [st1[0], st1[3]]
+    assert not bits_equal(want1, want)
+    with pytest.raises(F.FaldoiError):
+        ctx.match_growing(a, b, go, ba, preprocessed=1, split_img=1, first_h_parts=2, first_v_parts=1)
     with pytest.raises(F.FaldoiError):
         ctx.match_growing(a, b, go, ba, preprocessed=1, split_img=3)
 

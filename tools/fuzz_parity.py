@@ -88,6 +88,8 @@ def case_growing(rng):
     r = rng.random()
     if r < 0.4 and w >= 40 and h >= 40:
         split = dict(split_img=int(rng.integers(1, 3)), h_parts=int(rng.integers(1, 4)), v_parts=int(rng.integers(1, 4)))
+        if split["split_img"] == 2 and rng.random() < 0.5:
+            split.update(first_h_parts=int(rng.integers(1, 3)), first_v_parts=int(rng.integers(1, 3)))
     elif r < 0.6:
         sal = tuple(rng.uniform(0.2, 1.0, (h, w)).astype(np.float32) for _ in range(2))
     budget = int(rng.choice([16384, 257, 5000]))
@@ -96,7 +98,7 @@ def case_growing(rng):
             k, v = kv.split("=")
             if k == "budget":
                 budget = int(v)
-            elif k in ("split_img", "h_parts", "v_parts"):
+            elif k in ("split_img", "h_parts", "v_parts", "first_h_parts", "first_v_parts"):
                 split[k] = int(v)
             else:
                 prm[k] = float(v) if k == "fb_thresh" else int(v)

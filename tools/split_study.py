@@ -53,9 +53,15 @@ def epe(x, y):
 runs = [("whole", {})]
 for c in a.configs.split(";"):
     if c:
-        mode, grid = c.split(":")
+        mode, grid = c.split(":")[:2]
         hp, vp = (int(v) for v in grid.split(","))
-        runs.append(("split%s_%dx%d" % (mode, hp, vp), dict(split_img=int(mode), h_parts=hp, v_parts=vp)))
+        kw = dict(split_img=int(mode), h_parts=hp, v_parts=vp)
+        label = "split%s_%dx%d" % (mode, hp, vp)
+        if c.count(":") == 2:                      # mode:H,V:FH,FV = the grid of local iteration 0
+            fh, fv = (int(v) for v in c.split(":")[2].split(","))
+            kw.update(first_h_parts=fh, first_v_parts=fv)
+            label += "_first%dx%d" % (fh, fv)
+        runs.append((label, kw))
 keep = {}
 base_local = base_final = None
 for label, kw in runs:
