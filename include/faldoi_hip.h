@@ -231,7 +231,7 @@ int faldoi_tvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, floa
 /* src/global_faldoi.cpp:906-932 image_to_lab: planar R,G,B (0..255) -> planar L,a*,b* (host, libm). */
 int faldoi_image_to_lab(const float *rgb, int nx, int ny, float *lab);
 
-/* ---- the local step: match_growing_variational, src/local_faldoi.cpp:1060-1741 (-m 0 / 1, -split_img 0 / 1) ----
+/* ---- the local step: match_growing_variational, src/local_faldoi.cpp:1060-1741 (-m 0 / 1, -split_img 0 / 1 / 2) ----
  * Seeds -> priority-queue growing (forward and backward) -> forward-backward pruning -> re-seeding,
  * `iterations_of` times, then a last forward growing.  Argument order follows the reference function:
  * go / ba = seed flows (2 planes each, NaN = no seed), i0 / i1 = frames (planar, pd channels, 0..255; or
