@@ -182,7 +182,7 @@ static bool tile_supported(int r, int w)
            (r == 8 && w == 8) || (r == 2 && w == 16);
 }
 
-// Tile shape and iterations per launch.  Measured on MI355X (tools/sweep.py, 1024x436 pairs):
+// Tile shape and iterations per launch.  Measured on MI355X (tests/tools/sweep.py, 1024x436 pairs):
 //   * while the 64x64 / k=10 tiling yields at most one tile per CU (a single pair of this size:
 //     240 tiles on 256 CUs) it is the fastest -- fewest launches, all CUs busy once;
 //   * with more tiles than CUs (batches, large frames) occupancy is no longer the constraint and

@@ -452,7 +452,7 @@ def test_nan_flow_spreads_like_in_the_reference(ctx, oracle):
     # A NaN in the flow (windows over pruned pixels that no fill touched; a NaN in an initial flow) makes the norm of
     # that pixel's duals NaN one iteration later, and the reference's MAX(1, xi_N) macro then yields NaN for all
     # four duals of the pixel, not only the NaN ones: the set of NaN pixels after k iterations must be the same
-    # (found by tools/fuzz_parity.py: one window energy finite instead of NaN, two more candidates in a queue).
+    # (found by tests/tools/fuzz_parity.py: one window energy finite instead of NaN, two more candidates in a queue).
     i0n, i1n, gt = synthetic_pair(96, 64, seed=9)
     rng = np.random.default_rng(4)
     u0 = (gt + rng.standard_normal(gt.shape) * 0.3).astype(np.float32)

@@ -2,7 +2,7 @@
 
 Wider than tests/ (which pins chosen cases): every case draws its frame size, crop, seeds and parameters from a seeded
 generator, so a failure is reproducible from the printed case number.  Runs on the GPU box:
-    python tools/fuzz_parity.py [--family tvl1,growing,tvcsad,nltv] [--cases 200] [--seed 0] [--minutes 10]"""
+    python tests/tools/fuzz_parity.py [--family tvl1,growing,tvcsad,nltv] [--cases 200] [--seed 0] [--minutes 10]"""
 import argparse
 import os
 import sys
@@ -11,7 +11,7 @@ import traceback
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, ROOT)
 import faldoi_ipol_amd as F  # noqa: E402

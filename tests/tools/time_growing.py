@@ -1,5 +1,5 @@
 """Times the local step (match growing) on the GPU and, optionally, the CPU checker on the same seeds.
-usage: python tools/time_growing.py [--crop x0,y0,w,h] [--frac 0.01] [--pairs 1] [--cpu] [--budget N]"""
+usage: python tests/tools/time_growing.py [--crop x0,y0,w,h] [--frac 0.01] [--pairs 1] [--cpu] [--budget N]"""
 import argparse
 import sys
 import time
@@ -7,7 +7,7 @@ import time
 import numpy as np
 
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, ROOT)
 import faldoi_ipol_amd as F  # noqa: E402
