@@ -442,6 +442,18 @@ def test_local_patch_operator_sequence_bit_exact(ctx, oracle):
     g.close()
 
 
+def test_tvl1_uhd_frame_bit_exact(ctx, oracle):
+    # a 3840x2160 frame (8.3 Mpx, 4 000+ tiles: the many-tiles schedule, 64-bit plane offsets): same bits as the CPU path
+    w, h = 3840, 2160
+    i0n, i1n, gt = synthetic_pair(w, h, seed=77, amp=3.0)
+    u0 = (gt * np.float32(0.5)).astype(np.float32)
+    want, wit, werr, wxi = oracle.tvl1_global(i0n, i1n, u0, warps=2, max_inner=12, tol_stop=True, tol=0.05)
+    got, git, gerr, gxi, _ = ctx.tvl1_global(i0n, i1n, u0, xi=np.zeros((4, h, w), np.float32), warps=2, max_inner=12, tol_stop=1, tol=0.05)
+    assert np.array_equal(git, wit) and bits_equal(gerr, werr)
+    assert bits_equal(got, want), mismatch_report(got, want)
+    assert bits_equal(gxi, wxi)
+
+
 def _same_up_to_nan_payload(a, b):
     a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
     na, nb = np.isnan(a), np.isnan(b)
