@@ -22,6 +22,7 @@ ap.add_argument("--budget", type=int, default=16384)
 ap.add_argument("--loc_it", type=int, default=3)
 ap.add_argument("--split", default="", help="H,V[,mode]: image partitions (-split_img mode -h_parts H -v_parts V; mode 1 or 2)")
 ap.add_argument("--verbose", type=int, default=0)
+ap.add_argument("--scale", type=int, default=1, help="enlarge the frames k times (bicubic-free pixel repetition + smoothing by the preprocessing)")
 ap.add_argument("--hard", action="store_true", help="the final/hard example pair (large motion) instead of clean/easy")
 a = ap.parse_args()
 crop = tuple(int(v) for v in a.crop.split(",")) if a.crop else None
@@ -29,6 +30,9 @@ i0, i1 = util.sintel_pair(crop)
 if a.hard:
     i0 = util.load_rgb_planar(os.path.join(util.GOLDEN, "sintel_final_hard_frame_0002.png"), crop)
     i1 = util.load_rgb_planar(os.path.join(util.GOLDEN, "sintel_final_hard_frame_0003.png"), crop)
+if a.scale > 1:
+    i0 = np.ascontiguousarray(np.repeat(np.repeat(i0, a.scale, axis=1), a.scale, axis=2))
+    i1 = np.ascontiguousarray(np.repeat(np.repeat(i1, a.scale, axis=1), a.scale, axis=2))
 ctx = F.Context()
 i0n, i1n = ctx.preprocess_local(i0, i1)
 h, w = i0n.shape
