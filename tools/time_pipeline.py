@@ -34,7 +34,8 @@ ctx.close()
 open(os.path.join(tmp, "ims.txt"), "w").write(f2 + "\n" + f3 + "\n")
 exe = F.build.build_host()["faldoi_flow"]
 for extra in ([], ["-split_img", "1", "-h_parts", "3", "-v_parts", "2"], ["-split_img", "2", "-h_parts", "3", "-v_parts", "2"],
-              ["-split_img", "2", "-h_parts", "8", "-v_parts", "6"]):
+              ["-split_img", "2", "-h_parts", "8", "-v_parts", "6"],
+              ["-split_img", "2", "-h_parts", "8", "-v_parts", "6", "-first_h_parts", "4", "-first_v_parts", "3"]):
     t = time.time()
     r = subprocess.run([exe, os.path.join(tmp, "ims.txt"), os.path.join(tmp, "m0.txt"), os.path.join(tmp, "m1.txt"),
                         os.path.join(tmp, "out.flo"), "-matcher", "cut", "-verbose", "1"] + extra, capture_output=True, text=True)
