@@ -23,26 +23,108 @@ WARPS, INNER = 300, 10
 BYTES_PER_PX_ITER = 76        # 19 fp32 planes touched once per inner iteration
 BYTES_PER_PX_WARP = 44        # per outer warp (bicubic gathers + constants)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# HBM bytes per launch of tvl1_chunk_kernel from rocprofv3 PMC passes (profiles/): filled in from the
-# committed counter summaries; None until measured for the current kernel.
-TRAFFIC_BYTES_PER_LAUNCH = 36303872   # (2*10739 + 13975) KB, profiles/r01_pmc_sq.md (1024x436, k=10)
+# NLTV-CSAD as built, fp32 planes touched per pixel-iteration by the two streaming kernels:
+#   nl_dual_kernel   reads p,q (48) + w (24) + wt + ubar1,ubar2 = 75, writes p,q (48)
+#   nl_primal_kernel reads p,q (48) + w (24) + wt + u1,u2,ubar.. (4) + I0,I1w,I1wx,I1wy,grad (5) + 2 warp products = 84,
+#                    writes u1,u2,ubar1,ubar2 (4)
+NLTV_BYTES_PER_PX_ITER = 4 * (75 + 48 + 84 + 4)
+VALU_PEAK_GINSTR = 1024 * 0.5 * 2.4   # 256 CUs x 4 SIMD-32 x one wave64 VALU instruction per 2 clk x 2.4 GHz (MI355X_MICROARCH.md)
+# rocprofv3 counter summaries of the kernels (per launch), written by tools/pmc_summary.py from the PMC passes
+# of the SAME bench command; nothing here is typed in by hand
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 
-def main():
+def load_counters():
+    try:
+        with open(COUNTERS_JSON) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def launcher_selftest(args, rank, world):
+    """The N-rank plumbing of this file with a stub step and the gloo backend (CPU test, tests/test_shard_cpu.py):
+    rendezvous, barrier-bracketed timing, MAX/SUM reduction, per-rank gather, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    import faldoi_ipol_amd as F
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        dist.init_process_group("gloo")
+    use = dist.is_initialized()
+    if use:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (rank + 1))
+    if use:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    units = float(args.steps * args.pairs_per_gpu)
+    dt_max, total = F.shard.reduce_timing(dt, units, dist if use else None, None)
+    per_rank = F.shard.gather_scalars(units / dt, dist if use else None, None)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher-selftest (stub step, not a measurement)", "n_gpus": world,
+                          "steps": args.steps, "units": total, "seconds_max": dt_max,
+                          "per_rank": per_rank, "ranks": len(per_rank)}), flush=True)
+    if use:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(ngpus, argv):
+    """`bench.py --gpus N` started as ONE plain process: start N ranks (one per GPU) under
+    torch.distributed.run as a fresh child and hand its output and exit code through.  Runs before torch or
+    the HIP library is imported, so this process never touches a GPU (a process that has initialised the
+    GPU must not be replaced or re-launched)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs-per-gpu", type=int, default=1)
+    ap.add_argument("--pairs-per-gpu", type=int, default=1,
+                    help="pairs resident on every GPU; 4 with --gpus 8 is BASELINE configs[3] (32 pairs on 8 GPUs)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--growing-pairs", type=int, default=512)
-    args = ap.parse_args()
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU test hook for the N-rank launcher: gloo backend, a stub step, no GPU; the line it "
+                         "prints is labelled as such and is not a measurement")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ or "TORCHELASTIC_RUN_ID" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU\n" % (args.gpus, world))
+        sys.exit(2)
+    if args.launcher_selftest:
+        return launcher_selftest(args, rank, world)
 
     import numpy as np
     import torch
@@ -104,142 +186,230 @@ def main():
 
     px_iters_local = float(args.steps) * npairs * W * H * WARPS * INNER
     dt_max, px_iters = F.shard.reduce_timing(dt, px_iters_local, dist if use_dist else None, dev)
+    per_rank = F.shard.gather_scalars(px_iters_local / dt / 1e6, dist if use_dist else None, dev)
 
-    # Duration of the dominant kernel itself (outside the timed region): one more solve with a HIP
-    # event pair around every launch of the fused iteration kernel, on the library's own stream.
-    kernel_us = None
+    # Durations of the two kernels of a step (outside the timed region), from whole-solve HIP-event times on the
+    # library's own stream: the per-warp kernel is idempotent, so a solve that launches it twice per warp
+    # (FALDOI_WARP_REPEAT=2) returns the same bits and takes exactly `warps` warp-kernel durations longer.
+    #   warp_us = (T2 - T1) / warps ;  chunk_us = (T1 - warps * warp_us - setup) / chunk launches
+    # No event sits between kernels (an event pair around every launch inflated it by ~7 % in round 1).
+    kern = None
     if rank == 0:
-        os.environ["FALDOI_EVENT_TIMING"] = "1"
-        step()
-        os.environ["FALDOI_EVENT_TIMING"] = "0"
-        _, nl1, _, chunk_ms = batch.last_timing()
-        if chunk_ms > 0:
-            kernel_us = chunk_ms * 1e3 / nl1
+        reps = max(3, min(args.steps, 10))
+        t1 = min(step()[2] for _ in range(reps))
+        os.environ["FALDOI_WARP_REPEAT"] = "2"
+        t2 = min(step()[2] for _ in range(reps))
+        os.environ["FALDOI_WARP_REPEAT"] = "1"
+        nl1 = batch.last_timing()[1]
+        warp_us = max(0.0, (t2 - t1) * 1e3 / WARPS)
+        chunk_us = (t1 * 1e3 - WARPS * warp_us) / nl1
+        kern = dict(chunk_us=chunk_us, warp_us=warp_us, solve_ms=t1, launches=nl1, schedule=batch.last_schedule())
 
     out = None
     if rank == 0:
         value = px_iters / dt_max / 1e6
-        iters_per_launch = WARPS * INNER * args.steps / launches
-        # dominant kernel = tvl1_chunk_kernel: algorithmic bytes of the inner iterations one launch
-        # advances (76 B/px/iteration) over that launch's own duration
-        bytes_per_launch = npairs * W * H * BYTES_PER_PX_ITER * iters_per_launch
-        group_us = dev_ms * 1e3 / launches                 # whole solve / launches (incl. the per-warp kernel)
-        launch_us = kernel_us if kernel_us else group_us
-        achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-        out = {
-            "metric": "Mpixels*warp-iters/sec on TV-L1 global_faldoi, Sintel 1024x436; EPE vs CPU ref",
-            "value": round(value, 1), "unit": "Mpx*iter/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": data_kind if world == 1 and npairs == 1 else "rank 0 pair 0: " + data_kind + "; others synthetic",
-            "config": {"workload": "TV-L1 global minimisation, %d pair(s)/GPU of %dx%d, %d warps x %d inner "
-                                   "iterations, tolerance stop off (BASELINE configs[1])"
-                                   % (npairs, W, H, WARPS, INNER),
-                       "pairs_per_gpu": npairs, "parallelism": "pairs-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "tvl1_chunk_kernel",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": TRAFFIC_BYTES_PER_LAUNCH if (npairs == 1 and args.chunk in (0, 10)) else None,
-                         "launch_us": round(launch_us, 2), "launch_us_source":
-                             "HIP event pair around every launch" if kernel_us else "solve time / launches",
-                         "solve_us_per_launch_incl_warp_kernel": round(group_us, 2),
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "inner_iters_per_launch": round(iters_per_launch, 2)},
-        }
-        if world == 1 and data_kind != "synthetic" and not args.no_secondary:
-            # BASELINE configs[4] (not the headline): NLTV-CSAD, same pair, 1 warp x 400 iterations
-            lab = F.capi.image_to_lab(load_rgb_planar(f2))
-            i0n, i1n, u0 = pairs[0]
-            ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=20)            # warm-up
-            _, nl_ms = ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=400)
-            out["secondary"] = {"nltvcsad_1024x436_1warp_x_400": {
-                "device_ms": round(nl_ms, 2), "Mpx_iter_per_s": round(W * H * 400 / nl_ms / 1e3, 1),
-                "algorithmic_GBps": round(720.0 * W * H * 400 / (nl_ms * 1e-3) / 1e9, 1),
-                "note": "two streaming launches per iteration, ~720 B/px/iteration (SURVEY 8d, approximate)"}}
-        if world == 1 and data_kind != "synthetic" and not args.no_secondary:
-            # SURVEY 8f-1 (not the headline): the local step (match growing).  One growing is a sequential
-            # priority-queue process (one workgroup each); the device runs the growings of many pairs at once.
-            gp, gw, gh = args.growing_pairs, 256, 192
-            full0, full1 = load_rgb_planar(f2), load_rgb_planar(f3)
-            rng = np.random.default_rng(7)
-            g_i0, g_i1, g_go, g_ba = [], [], [], []
-            for k in range(gp):
-                x0, y0 = (k * 37) % (W - gw), (k * 53) % (H - gh)
-                c0 = np.ascontiguousarray(full0[:, y0:y0 + gh, x0:x0 + gw])
-                c1 = np.ascontiguousarray(full1[:, y0:y0 + gh, x0:x0 + gw])
-                a, b = ctx.preprocess_local(c0, c1)
-                sd = []
-                for src, dst in ((a, b), (b, a)):           # seeds: ~1 % of a dense TV-L1 flow, rounded (matcher-like)
-                    dense = ctx.tvl1_global(src, dst, np.zeros((2, gh, gw), np.float32), warps=3)[0]
-                    sp = np.full_like(dense, np.nan)
-                    m = rng.random((gh, gw)) < 0.011
-                    sp[:, m] = np.round(dense[:, m])
-                    sd.append(sp)
-                g_i0.append(c0); g_i1.append(c1); g_go.append(sd[0]); g_ba.append(sd[1])
-            g_out, _, gst = ctx.match_growing_batch(g_i0, g_i1, g_go, g_ba)
-            windows = int(sum(gst.solves))
-            grow = {"pairs": gp, "size": "%dx%d" % (gw, gh), "windows": windows, "device_ms": round(gst.growing_ms, 1),
-                    "windows_per_s": round(windows / (gst.growing_ms * 1e-3), 0),
-                    "note": "seeds -> 3 x (growing fwd+bwd, FB pruning, re-seeding) -> last growing; every candidate on the "
-                            "device, in the reference's order"}
-            if not args.no_cpu_baseline:
-                from oracle import oracle as O
-                a, b = O.preprocess_local(g_i0[0], g_i1[0])
-                t1 = time.perf_counter()
-                want, _, ost = O.local_faldoi(a, b, g_go[0], g_ba[0])
-                cpu_s = time.perf_counter() - t1
-                grow["cpu_windows_per_s"] = round((ost[1] + ost[4]) / cpu_s, 0)
-                grow["cpu_sample"] = "pair 0 once, forward and backward on 2 threads (%.1f s)" % cpu_s
-                grow["bit_identical_pair0"] = bool(np.array_equal(g_out[0].view(np.uint32), want.view(np.uint32)))
-            out.setdefault("secondary", {})["local_match_growing"] = grow
-            # one full-size pair: a single growing is sequential, so one pair only gets fast on image partitions
-            # (-split_img 2, additive: partitions from the first local iteration on)
-            a, b = ctx.preprocess_local(full0, full1)
-            sd = []
-            for src, dst in ((a, b), (b, a)):
-                dense = ctx.tvl1_global(src, dst, np.zeros((2, H, W), np.float32), warps=5)[0]
-                sp = np.full_like(dense, np.nan)
-                m = rng.random((H, W)) < 0.011
-                sp[:, m] = np.round(dense[:, m])
-                sd.append(sp)
-            _, _, st1 = ctx.match_growing(full0, full1, sd[0], sd[1], split_img=2, h_parts=8, v_parts=6)
-            out["secondary"]["local_match_growing_one_pair"] = {
-                "size": "%dx%d" % (W, H), "mode": "-split_img 2 -h_parts 8 -v_parts 6 (96 growings in flight)",
-                "windows": int(sum(st1.solves)), "device_ms": round(st1.growing_ms, 1),
-                "windows_per_s": round(sum(st1.solves) / (st1.growing_ms * 1e-3), 0),
-                "note": "whole-image growings (the reference's default): 34 s for the same pair; its own -split_img 1 "
-                        "with 3x2 partitions: 16 s (tools/split_study.py)"}
+        out = headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, dev_ms, launches)
+        sys.stderr.write("bench headline: %s\n" % json.dumps({k: out[k] for k in ("value", "unit", "n_gpus", "ms_per_step")}))
+        sys.stderr.flush()
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle as O            # checker + timed CPU baseline only
-            i0n, i1n, u0 = pairs[0]
-            O.lib()
-            t1 = time.perf_counter()
-            ou, oit, _, _ = O.tvl1_global(i0n, i1n, u0, warps=WARPS, max_inner=INNER, tol_stop=False)
-            cpu_s = time.perf_counter() - t1
-            gu = batch.download(0)
-            epe = float(F.flo.epe(gu, ou).mean())
-            out["cpu_baseline"] = {"value": round(W * H * WARPS * INNER / cpu_s / 1e6, 1), "unit": "Mpx*iter/s",
-                                   "cores": int(O.lib().orc_num_threads()), "kind": "port",
-                                   "sample": "the full step once (1 pair, %d warps x %d iterations, %.1f s)"
-                                             % (WARPS, INNER, cpu_s)}
-            # SURVEY 8d also asks for the one-thread figure: a tenth of the schedule (30 warps x 10 iterations)
-            nthreads = int(O.lib().orc_num_threads())
-            O.lib().orc_set_num_threads(1)
-            t1 = time.perf_counter()
-            O.tvl1_global(i0n, i1n, u0, warps=WARPS // 10, max_inner=INNER, tol_stop=False)
-            cpu1_s = time.perf_counter() - t1
-            O.lib().orc_set_num_threads(nthreads)
-            out["cpu_baseline_1thread"] = {"value": round(W * H * (WARPS // 10) * INNER / cpu1_s / 1e6, 1), "unit": "Mpx*iter/s",
-                                           "cores": 1, "kind": "port",
-                                           "sample": "%d warps x %d iterations of the same pair (%.1f s)" % (WARPS // 10, INNER, cpu1_s)}
-            out["epe_vs_cpu"] = {"mean_epe_px": epe, "bit_identical": bool(
-                np.array_equal(gu.view(np.uint32), ou.view(np.uint32))), "gate": 1e-4}
+            guarded(out, "cpu_baseline", lambda: cpu_baseline_leg(out, F, np, batch, pairs))
+        if world == 1 and data_kind != "synthetic" and not args.no_secondary:
+            guarded(out, "nltvcsad", lambda: nltvcsad_leg(out, F, np, ctx, pairs, load_rgb_planar(f2)))
+            guarded(out, "local_step", lambda: local_step_leg(out, args, F, np, ctx, load_rgb_planar(f2), load_rgb_planar(f3)))
         print(json.dumps(out), flush=True)
     batch.close()
     ctx.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def guarded(out, name, fn):
+    """A secondary leg must never cost the headline line: its failure is recorded, not raised."""
+    try:
+        fn()
+    except Exception as e:                      # noqa: BLE001 -- reported in the JSON line
+        out.setdefault("secondary_errors", {})[name] = "%s: %s" % (type(e).__name__, e)
+
+
+def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, dev_ms, launches):
+    iters_per_launch = WARPS * INNER * args.steps / launches
+    px = npairs * W * H
+    group_us = dev_ms * 1e3 / launches                     # whole solve / chunk launches (incl. the per-warp kernel)
+    chunk_us = kern["chunk_us"]
+    warp_us = kern["warp_us"]
+    R, NW, K = kern["schedule"]
+    cnt = load_counters()
+    ck = cnt.get("tvl1_chunk_kernel", {})
+    wk = cnt.get("tvl1_warp_kernel", {})
+    same = (ck.get("tile") == [R, NW] and ck.get("chunk") == K and ck.get("pairs") == npairs and ck.get("size") == [W, H])
+    valu = ck.get("SQ_INSTS_VALU") if same else None
+    traffic = int((2 * ck["FETCH_SIZE_KB"] + ck["WRITE_SIZE_KB"]) * 1024) if same and "FETCH_SIZE_KB" in ck else None
+    algo_bytes = px * BYTES_PER_PX_ITER * iters_per_launch
+    step_bytes = px * (BYTES_PER_PX_ITER * WARPS * INNER + BYTES_PER_PX_WARP * WARPS)
+    # useful pixel-iterations / computed ones: a 64 x TH tile advanced K iterations owns (64-2K) x (TH-2K) pixels
+    TH = R * NW
+    own_frac = (64 - 2 * K) * (TH - 2 * K) / float(64 * TH)
+    roof = {"bound": "valu", "kernel": "tvl1_chunk_kernel<%d,%d>" % (R, NW),
+            "achieved": round(valu / (chunk_us * 1e-6) / 1e9, 1) if valu else None,
+            "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+            "frac": round(valu / (chunk_us * 1e-6) / 1e9 / VALU_PEAK_GINSTR, 4) if valu else None,
+            "traffic": traffic,
+            "launch_us": round(chunk_us, 2),
+            "launch_us_source": "HIP events around whole solves on the library's stream; solve(warp kernel x2) - solve = "
+                                "warps x warp kernel; the rest / chunk launches",
+            "launch_us_rocprof": ck.get("avg_us") if same else None,
+            "valu_instr_per_launch": valu, "valu_instr_per_useful_px_iter":
+                round(valu * 64 / (px * iters_per_launch), 1) if valu else None,
+            "owned_over_computed_px": round(own_frac, 3),
+            "inner_iters_per_launch": round(iters_per_launch, 2),
+            "counters_file": os.path.relpath(COUNTERS_JSON, ROOT) if same else None,
+            "note": "register-resident temporal blocking: the kernel is bound by vector-ALU issue, not by HBM "
+                    "(see roofline_hbm for the HBM view the north star asks for)"}
+    hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "chunk_kernel": {
+               "algorithmic_bytes_per_launch": int(algo_bytes),
+               "effective_GBps": round(algo_bytes / (chunk_us * 1e-6) / 1e9, 1),
+               "effective_frac": round(algo_bytes / (chunk_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+               "measured_traffic_bytes_per_launch": traffic,
+               "measured_GBps": round(traffic / (chunk_us * 1e-6) / 1e9, 1) if traffic else None,
+               "measured_frac": round(traffic / (chunk_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+               "note": "effective = 76 B/px/iteration x pixels x iterations per launch / launch time; it may exceed the "
+                       "peak because %d iterations run from registers per pass over HBM" % K},
+           "warp_kernel": {
+               "launch_us": round(warp_us, 2), "launch_us_rocprof": wk.get("avg_us"),
+               "algorithmic_bytes_per_launch": int(px * BYTES_PER_PX_WARP),
+               "GBps": round(px * BYTES_PER_PX_WARP / (warp_us * 1e-6) / 1e9, 1) if warp_us > 0 else None,
+               "frac": round(px * BYTES_PER_PX_WARP / (warp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if warp_us > 0 else None,
+               "measured_traffic_bytes_per_launch":
+                   int((2 * wk["FETCH_SIZE_KB"] + wk["WRITE_SIZE_KB"]) * 1024) if "FETCH_SIZE_KB" in wk else None},
+           "whole_step": {
+               "algorithmic_bytes": int(step_bytes), "ms": round(kern["solve_ms"], 3),
+               "effective_GBps": round(step_bytes / (kern["solve_ms"] * 1e-3) / 1e9, 1),
+               "effective_frac": round(step_bytes / (kern["solve_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    if roof["frac"] is not None:
+        assert roof["frac"] <= 1.0, "VALU roofline fraction above 1: counters file does not belong to this kernel"
+    return {
+        "metric": "Mpixels*warp-iters/sec on TV-L1 global_faldoi, Sintel 1024x436; EPE vs CPU ref",
+        "value": round(value, 1), "unit": "Mpx*iter/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": data_kind if world == 1 and npairs == 1 else "rank 0 pair 0: " + data_kind + "; others synthetic",
+        "config": {"workload": "TV-L1 global minimisation, %d pair(s)/GPU of %dx%d, %d warps x %d inner "
+                               "iterations, tolerance stop off (BASELINE configs[1]%s)"
+                               % (npairs, W, H, WARPS, INNER,
+                                  "; %d pairs over %d GPUs = configs[3] shape" % (npairs * world, world) if world > 1 else ""),
+                   "pairs_per_gpu": npairs, "parallelism": "pairs-sharded x%d" % world,
+                   "ranks": len(per_rank), "collectives": "RCCL barrier + MAX/SUM of two scalars; none on the data path"},
+        "per_rank_Mpx_iter_per_s": [round(v, 1) for v in per_rank],
+        "roofline": roof, "roofline_hbm": hbm,
+        "solve_us_per_launch_incl_warp_kernel": round(group_us, 2),
+    }
+
+
+def cpu_baseline_leg(out, F, np, batch, pairs):
+    from oracle import oracle as O            # checker + timed CPU baseline only
+    i0n, i1n, u0 = pairs[0]
+    O.lib()
+    t1 = time.perf_counter()
+    ou, oit, _, _ = O.tvl1_global(i0n, i1n, u0, warps=WARPS, max_inner=INNER, tol_stop=False)
+    cpu_s = time.perf_counter() - t1
+    gu = batch.download(0)
+    epe = float(F.flo.epe(gu, ou).mean())
+    out["cpu_baseline"] = {"value": round(W * H * WARPS * INNER / cpu_s / 1e6, 1), "unit": "Mpx*iter/s",
+                           "cores": int(O.lib().orc_num_threads()), "kind": "port",
+                           "sample": "the full step once (1 pair, %d warps x %d iterations, %.1f s); the port fuses the "
+                                     "reference's 7 passes per iteration into 2 (the reference itself: ~108 Mpx*iter/s on "
+                                     "8 threads, SURVEY section 6)" % (WARPS, INNER, cpu_s)}
+    # SURVEY 8d also asks for the one-thread figure: a tenth of the schedule (30 warps x 10 iterations)
+    nthreads = int(O.lib().orc_num_threads())
+    O.lib().orc_set_num_threads(1)
+    t1 = time.perf_counter()
+    O.tvl1_global(i0n, i1n, u0, warps=WARPS // 10, max_inner=INNER, tol_stop=False)
+    cpu1_s = time.perf_counter() - t1
+    O.lib().orc_set_num_threads(nthreads)
+    out["cpu_baseline_1thread"] = {"value": round(W * H * (WARPS // 10) * INNER / cpu1_s / 1e6, 1), "unit": "Mpx*iter/s",
+                                   "cores": 1, "kind": "port",
+                                   "sample": "%d warps x %d iterations of the same pair (%.1f s)" % (WARPS // 10, INNER, cpu1_s)}
+    out["epe_vs_cpu"] = {"mean_epe_px": epe, "bit_identical": bool(
+        np.array_equal(gu.view(np.uint32), ou.view(np.uint32))), "gate": 1e-4}
+
+
+def nltvcsad_leg(out, F, np, ctx, pairs, rgb0):
+    # BASELINE configs[4] (not the headline): NLTV-CSAD, same pair, 1 warp x 400 iterations
+    lab = F.capi.image_to_lab(rgb0)
+    i0n, i1n, u0 = pairs[0]
+    ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=20)            # warm-up
+    ua, nl_ms = ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=400)
+    ub, nl_ms2 = ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=400)
+    nl_ms = min(nl_ms, nl_ms2)
+    cnt = load_counters()
+    nb = NLTV_BYTES_PER_PX_ITER
+    leg = {"device_ms": round(nl_ms, 2), "Mpx_iter_per_s": round(W * H * 400 / nl_ms / 1e3, 1),
+           "algorithmic_bytes_per_px_iter": nb,
+           "algorithmic_GBps": round(nb * W * H * 400 / (nl_ms * 1e-3) / 1e9, 1),
+           "hbm_frac": round(nb * W * H * 400 / (nl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "deterministic_two_runs": bool(np.array_equal(ua.view(np.uint32), ub.view(np.uint32))),
+           "note": "two streaming launches per iteration; bytes per pixel-iteration of the layout actually built "
+                   "(DESIGN.md 3.4): dual kernel r 48 p,q + 24 w + wt + ub(2) / w 48; primal kernel r 48 + 24 + wt + "
+                   "u,ub(4) + I0,I1w,Ix,Iy,g + 2 warp products / w 4"}
+    for k in ("nl_primal_kernel", "nl_dual_kernel"):
+        if k in cnt and "FETCH_SIZE_KB" in cnt[k]:
+            leg[k] = {"avg_us": cnt[k].get("avg_us"),
+                      "measured_traffic_bytes_per_launch": int((2 * cnt[k]["FETCH_SIZE_KB"] + cnt[k]["WRITE_SIZE_KB"]) * 1024)}
+    out.setdefault("secondary", {})["nltvcsad_1024x436_1warp_x_400"] = leg
+
+
+def seeds_from_dense(ctx, np, rng, a, b, h, w, warps):
+    sd = []
+    for src, dst in ((a, b), (b, a)):           # seeds: ~1 % of a dense TV-L1 flow, rounded (matcher-like)
+        dense = ctx.tvl1_global(src, dst, np.zeros((2, h, w), np.float32), warps=warps)[0]
+        sp = np.full_like(dense, np.nan)
+        m = rng.random((h, w)) < 0.011
+        sp[:, m] = np.round(dense[:, m])
+        sd.append(sp)
+    return sd
+
+
+def local_step_leg(out, args, F, np, ctx, full0, full1):
+    # SURVEY 8f-1 (not the headline): the local step (match growing).  One growing is a sequential
+    # priority-queue process; the device runs the growings of many pairs at once.
+    gp, gw, gh = args.growing_pairs, 256, 192
+    rng = np.random.default_rng(7)
+    g_i0, g_i1, g_go, g_ba = [], [], [], []
+    for k in range(gp):
+        x0, y0 = (k * 37) % (W - gw), (k * 53) % (H - gh)
+        c0 = np.ascontiguousarray(full0[:, y0:y0 + gh, x0:x0 + gw])
+        c1 = np.ascontiguousarray(full1[:, y0:y0 + gh, x0:x0 + gw])
+        a, b = ctx.preprocess_local(c0, c1)
+        sd = seeds_from_dense(ctx, np, rng, a, b, gh, gw, 3)
+        g_i0.append(c0); g_i1.append(c1); g_go.append(sd[0]); g_ba.append(sd[1])
+    g_out, _, gst = ctx.match_growing_batch(g_i0, g_i1, g_go, g_ba)
+    windows = int(sum(gst.solves))
+    grow = {"pairs": gp, "size": "%dx%d" % (gw, gh), "windows": windows, "device_ms": round(gst.growing_ms, 1),
+            "windows_per_s": round(windows / (gst.growing_ms * 1e-3), 0),
+            "note": "seeds -> 3 x (growing fwd+bwd, FB pruning, re-seeding) -> last growing; every candidate on the "
+                    "device, in the reference's order"}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        a, b = O.preprocess_local(g_i0[0], g_i1[0])
+        t1 = time.perf_counter()
+        want, _, ost = O.local_faldoi(a, b, g_go[0], g_ba[0])
+        cpu_s = time.perf_counter() - t1
+        grow["cpu_windows_per_s"] = round((ost[1] + ost[4]) / cpu_s, 0)
+        grow["cpu_sample"] = "pair 0 once, forward and backward on 2 threads (%.1f s)" % cpu_s
+        grow["bit_identical_pair0"] = bool(np.array_equal(g_out[0].view(np.uint32), want.view(np.uint32)))
+    out.setdefault("secondary", {})["local_match_growing"] = grow
+    # one full-size pair in a REFERENCE mode (BASELINE configs[2] shape): the reference's own image partitions
+    # (-split_img 1 -h_parts 3 -v_parts 2); the whole-image default (-split_img 0) is timed by the -m gpu test
+    # test_full_size_pipeline_final_hard and quoted in DESIGN.md
+    a, b = ctx.preprocess_local(full0, full1)
+    sd = seeds_from_dense(ctx, np, rng, a, b, H, W, 5)
+    _, _, st1 = ctx.match_growing(full0, full1, sd[0], sd[1], split_img=1, h_parts=3, v_parts=2)
+    out["secondary"]["local_match_growing_one_pair"] = {
+        "size": "%dx%d" % (W, H), "mode": "-split_img 1 -h_parts 3 -v_parts 2 (the reference's partition mode)",
+        "windows": int(sum(st1.solves)), "device_ms": round(st1.growing_ms, 1),
+        "windows_per_s": round(sum(st1.solves) / (st1.growing_ms * 1e-3), 0)}
 
 
 if __name__ == "__main__":

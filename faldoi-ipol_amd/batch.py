@@ -87,6 +87,27 @@ def gather_flows(dist, torch, device, rank, world, flows_mine, shape):
     return res
 
 
+def load_jobs(path, F):
+    """Rank 0: decode every job's frames and flows.  Returns (jobs, frames uint8 (n,2,3,h,w), flows (n,2|4,h,w))."""
+    from PIL import Image
+    jobs = parse_jobs(path)
+    if not jobs:
+        raise ValueError("%s: no jobs" % path)
+    fr = [[np.asarray(Image.open(p).convert("RGB")).transpose(2, 0, 1) for p in job[:2]] for job in jobs]
+    if len({f.shape for pair in fr for f in pair}) != 1:
+        raise ValueError("%s: all frames of a batch must have one size" % path)
+    frames = np.ascontiguousarray(np.array(fr, dtype=np.uint8))
+    h, w = frames.shape[-2:]
+    if len(jobs[0]) == 5:
+        flows = [np.concatenate([F.flo.read_flo(job[2]), F.flo.read_flo(job[3])]) for job in jobs]
+    else:
+        flows = [np.zeros((2, h, w), np.float32) if job[2] == "zero" else F.flo.read_flo(job[2]) for job in jobs]
+    for job, fl in zip(jobs, flows):
+        if fl.shape[-2:] != (h, w):
+            raise ValueError("%s: flow of job %s is %dx%d, frames are %dx%d" % (path, job[-1], fl.shape[-1], fl.shape[-2], w, h))
+    return jobs, frames, np.stack(flows)
+
+
 def solve_shard_gpu(frames, flows, local_rank, local_params=None, **params):
     """frames (n,2,3,h,w) uint8, flows (n,2,h,w) -> refined flows (n,2,h,w) + per-pair iteration counts."""
     import faldoi_ipol_amd as F
@@ -143,18 +164,20 @@ def main(argv=None):
     meta = [None]
     frames = flows = None
     if rank == 0:
-        from PIL import Image
-        jobs = parse_jobs(argv[0])
-        fr = [[np.asarray(Image.open(p).convert("RGB")).transpose(2, 0, 1) for p in job[:2]] for job in jobs]
-        frames = np.ascontiguousarray(np.array(fr, dtype=np.uint8))
-        h, w = frames.shape[-2:]
-        if len(jobs[0]) == 5:
-            flows = np.stack([np.concatenate([F.flo.read_flo(job[2]), F.flo.read_flo(job[3])]) for job in jobs])
-        else:
-            flows = np.stack([np.zeros((2, h, w), np.float32) if job[2] == "zero" else F.flo.read_flo(job[2])
-                              for job in jobs])
-        meta = [(len(jobs), h, w, [job[-1] for job in jobs], flows.shape[1])]
+        # a failure while reading the inputs must not leave the other ranks blocked in the broadcast:
+        # rank 0 always broadcasts, either the job table or an error marker, and every rank leaves together
+        try:
+            jobs, frames, flows = load_jobs(argv[0], F)
+            h, w = frames.shape[-2:]
+            meta = [(len(jobs), h, w, [job[-1] for job in jobs], flows.shape[1])]
+        except Exception as e:                                   # noqa: BLE001 -- forwarded to every rank
+            meta = [("error", "%s: %s" % (type(e).__name__, e))]
     dist.broadcast_object_list(meta, src=0)                     # the job table
+    if meta[0][0] == "error":
+        if rank == 0:
+            sys.stderr.write("batch: cannot read the jobs: %s\n" % meta[0][1])
+        dist.destroy_process_group()
+        raise SystemExit(3)
     njobs, h, w, outs, planes = meta[0]
     my_fr, my_fl = scatter_inputs(dist, torch, device, rank, world, frames, flows, (njobs, h, w, planes))
     res, iters = solve_shard_gpu(my_fr, my_fl, local_rank, local_params=local_params, **params)

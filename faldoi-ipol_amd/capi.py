@@ -21,7 +21,7 @@ EXPORTS = [
     "faldoi_ctx_synchronize", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
     "faldoi_tvl1_batch_create", "faldoi_tvl1_batch_destroy", "faldoi_tvl1_batch_upload",
     "faldoi_tvl1_batch_reset", "faldoi_tvl1_batch_solve", "faldoi_tvl1_batch_download",
-    "faldoi_tvl1_batch_last_timing", "faldoi_centered_gradient", "faldoi_forward_gradient",
+    "faldoi_tvl1_batch_last_timing", "faldoi_tvl1_batch_last_schedule", "faldoi_centered_gradient", "faldoi_forward_gradient",
     "faldoi_divergence", "faldoi_bicubic_warp", "faldoi_selftest_division",
     "faldoi_preprocess_global", "faldoi_tvl1_batch_upload_images",
     "faldoi_nltvcsad_default_params", "faldoi_nltvcsad_global", "faldoi_image_to_lab",
@@ -112,6 +112,7 @@ def lib():
     L.faldoi_tvl1_batch_download.argtypes = [vp, C.c_int, _F, vp]
     L.faldoi_tvl1_batch_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                                 C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    L.faldoi_tvl1_batch_last_schedule.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.faldoi_centered_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_forward_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_divergence.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
@@ -294,15 +295,30 @@ class Context:
             setattr(p, {"wr": "w_radio", "loc_it": "iterations_of", "fb_thresh": "epsilon"}.get(k, k), v)
         return p
 
+    @staticmethod
+    def _check_pair_shapes(i0, i1, go, ba, sal0=None, sal1=None, what="pair"):
+        """The C ABI takes raw pointers and ONE (nx, ny, pd): every array of a pair must have that shape."""
+        if i0.ndim not in (2, 3):
+            raise ValueError("%s: frames must be (h,w) or (pd,h,w), got %s" % (what, i0.shape))
+        h, w = i0.shape[-2:]
+        if i1.shape != i0.shape:
+            raise ValueError("%s: i1 has shape %s, i0 has %s" % (what, i1.shape, i0.shape))
+        for name, a in (("go", go), ("ba", ba)):
+            if a.shape != (2, h, w):
+                raise ValueError("%s: %s has shape %s, expected %s" % (what, name, a.shape, (2, h, w)))
+        for name, a in (("sal0", sal0), ("sal1", sal1)):
+            if a is not None and a.shape != (h, w):
+                raise ValueError("%s: %s has shape %s, expected %s" % (what, name, a.shape, (h, w)))
+        return (1 if i0.ndim == 2 else i0.shape[0]), h, w
+
     def match_growing(self, i0, i1, go, ba, sal0=None, sal1=None, **params):
         """Mirror of match_growing_variational (-m 0, no partitions).  i0/i1: (pd,h,w) frames 0..255, or normalised
         (h,w) planes with preprocessed=1.  go/ba: (2,h,w) seed flows, NaN = no seed.
         Returns (out_flow (2,h,w), ene_val (h,w), LocalStats)."""
         i0, i1, go, ba = _f32(i0), _f32(i1), _f32(go), _f32(ba)
-        pd = 1 if i0.ndim == 2 else i0.shape[0]
-        h, w = i0.shape[-2:]
         sal0 = None if sal0 is None else _f32(sal0)
         sal1 = None if sal1 is None else _f32(sal1)
+        pd, h, w = self._check_pair_shapes(i0, i1, go, ba, sal0, sal1)
         out, ene, st = np.empty((2, h, w), np.float32), np.empty((h, w), np.float32), LocalStats()
         p = self._local_params(params)
         _check(lib().faldoi_match_growing_variational(self._h, go, ba, i0, i1, _ptr(sal0), _ptr(sal1), w, h, pd,
@@ -313,8 +329,12 @@ class Context:
         """Several pairs of one size at once: lists of arrays as in match_growing.  Returns (flows, energies, stats)."""
         k = len(i0s)
         i0s, i1s, gos, bas = ([_f32(a) for a in x] for x in (i0s, i1s, gos, bas))
-        pd = 1 if i0s[0].ndim == 2 else i0s[0].shape[0]
-        h, w = i0s[0].shape[-2:]
+        if k < 1 or not (len(i1s) == len(gos) == len(bas) == k):
+            raise ValueError("match_growing_batch: the four lists must have one entry per pair")
+        shapes = [self._check_pair_shapes(i0s[j], i1s[j], gos[j], bas[j], what="pair %d" % j) for j in range(k)]
+        if any(sh != shapes[0] for sh in shapes):
+            raise ValueError("match_growing_batch: all pairs must have one size and channel count, got %s" % sorted(set(shapes)))
+        pd, h, w = shapes[0]
         outs = [np.empty((2, h, w), np.float32) for _ in range(k)]
         enes = [np.empty((h, w), np.float32) for _ in range(k)]
 
@@ -433,6 +453,12 @@ class Tvl1Batch:
         ms, nl, pi, cms = C.c_double(), C.c_int(), C.c_long(), C.c_double()
         _check(lib().faldoi_tvl1_batch_last_timing(self._h, C.byref(ms), C.byref(nl), C.byref(pi), C.byref(cms)))
         return ms.value, nl.value, pi.value, cms.value
+
+    def last_schedule(self):
+        """(rows per thread, waves per workgroup, inner iterations per launch) of the last solve."""
+        r, nw, k = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().faldoi_tvl1_batch_last_schedule(self._h, C.byref(r), C.byref(nw), C.byref(k)))
+        return r.value, nw.value, k.value
 
     def download(self, pair, want_xi=False):
         u = np.empty((2, self.h, self.w), np.float32)

@@ -47,6 +47,59 @@ static int fail(int code, const char *fmt, ...)
                         "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// ------------------------------------------------------------------------------------------ ABI hygiene
+namespace {
+// Host containers may throw; nothing crosses the C ABI.
+template <typename Fn> int abi_guard(const char *what, Fn fn)
+{
+    try {
+        return fn();
+    } catch (const std::bad_alloc &) {
+        return fail(FALDOI_ERR_OOM, "out of host memory in %s", what);
+    } catch (const std::exception &e) {
+        return fail(FALDOI_ERR_STATE, "%s: %s", what, e.what());
+    }
+}
+
+
+// Whatever a function enqueued on the stream may still read or write its local host containers when it
+// returns early on an error: drain the stream on every exit path (a no-op when it is already idle).
+struct StreamDrain {
+    hipStream_t s;
+    explicit StreamDrain(hipStream_t st) : s(st) {}
+    ~StreamDrain() { (void)hipStreamSynchronize(s); }
+    StreamDrain(const StreamDrain &) = delete;
+    StreamDrain &operator=(const StreamDrain &) = delete;
+};
+
+// Runs fn(0 .. ntasks-1) on the host's threads (at most 16: the CPU share of one GPU).  Returns false if a task threw
+// (out of host memory): nothing propagates out of a worker thread or across the C ABI.
+template <typename Fn> bool grow_host_parallel(int ntasks, Fn fn)
+{
+    std::atomic<bool> failed(false);
+    auto guarded = [&](int task) {
+        try { fn(task); } catch (...) { failed = true; }
+    };
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads < 2 || ntasks < 2) {
+        for (int t = 0; t < ntasks; ++t) guarded(t);
+        return !failed;
+    }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    try {
+        for (unsigned t = 0; t < nthreads && t < (unsigned)ntasks; ++t)
+            pool.emplace_back([&] { for (int task; (task = next.fetch_add(1)) < ntasks;) guarded(task); });
+    } catch (...) {                                      // could not start (more) threads: the caller's thread finishes the list
+        for (int task; (task = next.fetch_add(1)) < ntasks;) guarded(task);
+    }
+    for (std::thread &t : pool) t.join();
+    return !failed;
+}
+
+}  // namespace
+
 // ------------------------------------------------------------------------------------------ types
 namespace {
 struct DevBuf {
@@ -81,6 +134,7 @@ struct faldoi_tvl1_batch {
     double last_ms = 0.0;
     double last_chunk_ms = 0.0;       // sum of per-launch event times of the fused kernel (0 = not measured)
     int last_launches = 0;
+    int last_tile_r = 0, last_tile_nw = 0, last_chunk = 0;   // schedule of the last solve
     long last_px_iters = 0;
     std::vector<hipEvent_t> ev;       // per-launch event pairs (only when FALDOI_EVENT_TIMING=1)
 };
@@ -248,7 +302,7 @@ static void launch_warp(int variant, dim3 grid, hipStream_t s, float *base, size
 }
 
 // ------------------------------------------------------------------------------------------ batch
-extern "C" int faldoi_tvl1_batch_create(faldoi_ctx *ctx, int npairs, int nx, int ny, faldoi_tvl1_batch **out)
+static int faldoi_tvl1_batch_create_impl(faldoi_ctx *ctx, int npairs, int nx, int ny, faldoi_tvl1_batch **out)
 {
     if (!ctx || !out) return fail(FALDOI_ERR_INVALID, "ctx/out is NULL");
     *out = nullptr;
@@ -279,6 +333,11 @@ extern "C" int faldoi_tvl1_batch_create(faldoi_ctx *ctx, int npairs, int nx, int
     return FALDOI_OK;
 }
 
+extern "C" int faldoi_tvl1_batch_create(faldoi_ctx *ctx, int npairs, int nx, int ny, faldoi_tvl1_batch **out)
+{
+    return abi_guard("the batch allocation", [&] { return faldoi_tvl1_batch_create_impl(ctx, npairs, nx, ny, out); });
+}
+
 extern "C" void faldoi_tvl1_batch_destroy(faldoi_tvl1_batch *b)
 {
     if (!b) return;
@@ -299,7 +358,7 @@ static float *plane_ptr(faldoi_tvl1_batch *b, int pair, int plane)
     return b->slabs + ((size_t)pair * P_COUNT + plane) * b->plane_elems;
 }
 
-extern "C" int faldoi_tvl1_batch_upload(faldoi_tvl1_batch *b, int pair, const float *I0, const float *I1,
+static int faldoi_tvl1_batch_upload_impl(faldoi_tvl1_batch *b, int pair, const float *I0, const float *I1,
                                         const float *u, const float *xi)
 {
     if (!b || !I0 || !I1 || !u) return fail(FALDOI_ERR_INVALID, "NULL argument");
@@ -323,6 +382,12 @@ extern "C" int faldoi_tvl1_batch_upload(faldoi_tvl1_batch *b, int pair, const fl
     return FALDOI_OK;
 }
 
+extern "C" int faldoi_tvl1_batch_upload(faldoi_tvl1_batch *b, int pair, const float *I0, const float *I1,
+                                        const float *u, const float *xi)
+{
+    return abi_guard("the batch upload", [&] { return faldoi_tvl1_batch_upload_impl(b, pair, I0, I1, u, xi); });
+}
+
 extern "C" int faldoi_tvl1_batch_reset(faldoi_tvl1_batch *b)
 {
     if (!b) return fail(FALDOI_ERR_INVALID, "batch is NULL");
@@ -341,7 +406,7 @@ static int ensure(void **p, size_t *have, size_t want_bytes)
     return FALDOI_OK;
 }
 
-extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, faldoi_tvl1_stats *stats)
+static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, faldoi_tvl1_stats *stats)
 {
     if (!b || !prm) return fail(FALDOI_ERR_INVALID, "NULL argument");
     for (int i = 0; i < b->npairs; ++i)
@@ -357,6 +422,8 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
     faldoi_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    b->solved = false;                          // a solve that fails midway leaves nothing to download
+    StreamDrain drain(s);                       // no early return leaves work in flight behind local host buffers
     TileCfg tc;
     int chunk;
     pick_schedule(b, prm, &tc, &chunk);
@@ -404,6 +471,8 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
     const dim3 wgrid(((npix + 255) / 256) * b->npairs);
     int wvariant = 4;                                  // waves/SIMD the per-warp kernel is compiled for
     if (const char *v = getenv("FALDOI_WARP_WPS")) wvariant = atoi(v);
+    int warp_repeat = 1;
+    if (const char *v = getenv("FALDOI_WARP_REPEAT")) { const int r = atoi(v); if (r >= 1 && r <= 8) warp_repeat = r; }
     int launches = 0;
     HIP_TRY(hipEventRecord(c->ev0, s));
     HIP_TRY(hipMemsetAsync(b->d_done, 0, sizeof(int), s));
@@ -440,7 +509,11 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
             while (n < prm->max_inner) {
                 const int it = (prm->max_inner - n) < chunk ? (prm->max_inner - n) : chunk;
                 if (n == 0) {
-                    launch_warp(wvariant, wgrid, s, b->slabs, b->plane_elems, b->nx, b->ny, b->npairs, b->ctl, 1, cur);
+                    // FALDOI_WARP_REPEAT=r (measurement aid): the per-warp kernel is idempotent -- it reads the flow and
+                    // writes the warp constants only -- so launching it r times changes no result; the difference of two
+                    // whole-solve times isolates its duration (bench.py)
+                    for (int r = 0; r < warp_repeat; ++r)
+                        launch_warp(wvariant, wgrid, s, b->slabs, b->plane_elems, b->nx, b->ny, b->npairs, b->ctl, 1, cur);
                     HIP_TRY(hipGetLastError());
                 }
                 if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
@@ -523,8 +596,16 @@ extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_p
     b->last_ms = ms;
     b->last_chunk_ms = chunk_ms;
     b->last_launches = launches;
+    b->last_tile_r = tc.R;
+    b->last_tile_nw = tc.NW;
+    b->last_chunk = chunk;
     b->last_px_iters = px_iters;
     return FALDOI_OK;
+}
+
+extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, faldoi_tvl1_stats *stats)
+{
+    return abi_guard("the TV-L1 solve", [&] { return faldoi_tvl1_batch_solve_impl(b, prm, stats); });
 }
 
 extern "C" int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *chunk_launches, long *px_iters,
@@ -536,6 +617,16 @@ extern "C" int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve
     if (chunk_launches) *chunk_launches = b->last_launches;
     if (px_iters) *px_iters = b->last_px_iters;
     if (chunk_kernel_ms) *chunk_kernel_ms = b->last_chunk_ms;
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_tvl1_batch_last_schedule(faldoi_tvl1_batch *b, int *rows_per_thread, int *waves, int *chunk)
+{
+    if (!b) return fail(FALDOI_ERR_INVALID, "batch is NULL");
+    if (!b->solved) return fail(FALDOI_ERR_STATE, "no solve has completed");
+    if (rows_per_thread) *rows_per_thread = b->last_tile_r;
+    if (waves) *waves = b->last_tile_nw;
+    if (chunk) *chunk = b->last_chunk;
     return FALDOI_OK;
 }
 
@@ -644,7 +735,7 @@ static int zoom_run(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny
     return FALDOI_OK;
 }
 
-extern "C" int faldoi_zoom_out(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, float factor)
+static int faldoi_zoom_out_impl(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, float factor)
 {
     if (!ctx || !I || !Iout) return fail(FALDOI_ERR_INVALID, "NULL argument");
     if (!(factor > 0.f) || !(factor < 1.f)) return fail(FALDOI_ERR_INVALID, "zoom factor %g outside (0,1)", (double)factor);
@@ -662,7 +753,12 @@ extern "C" int faldoi_zoom_out(faldoi_ctx *ctx, const float *I, float *Iout, int
     return zoom_run(ctx, I, Iout, nx, ny, nxx, nyy, factor, factor, &taps);
 }
 
-extern "C" int faldoi_zoom_in(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
+extern "C" int faldoi_zoom_out(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, float factor)
+{
+    return abi_guard("zoom_out", [&] { return faldoi_zoom_out_impl(ctx, I, Iout, nx, ny, factor); });
+}
+
+static int faldoi_zoom_in_impl(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
 {
     if (!ctx || !I || !Iout) return fail(FALDOI_ERR_INVALID, "NULL argument");
     int rc = prim_check(ctx, nx, ny);
@@ -670,6 +766,11 @@ extern "C" int faldoi_zoom_in(faldoi_ctx *ctx, const float *I, float *Iout, int 
     if (nxx < 1 || nyy < 1 || (long)nxx * nyy > (1L << 28)) return fail(FALDOI_ERR_INVALID, "bad zoomed size %dx%d", nxx, nyy);
     const float fx = ((float)nxx / nx), fy = ((float)nyy / ny);                         // src/zoom.c:92-93
     return zoom_run(ctx, I, Iout, nx, ny, nxx, nyy, fx, fy, nullptr);
+}
+
+extern "C" int faldoi_zoom_in(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
+{
+    return abi_guard("zoom_in", [&] { return faldoi_zoom_in_impl(ctx, I, Iout, nx, ny, nxx, nyy); });
 }
 
 // Device-side pipeline on three gray planes already in HBM (A = i0, B = i1, C = i_1), in place.
@@ -721,7 +822,7 @@ static int preprocess_check(faldoi_ctx *ctx, const float *i0, const float *i1, i
     return FALDOI_OK;
 }
 
-extern "C" int faldoi_preprocess_global(faldoi_ctx *ctx, const float *i0, const float *i1, const float *im1, int nx,
+static int faldoi_preprocess_global_impl(faldoi_ctx *ctx, const float *i0, const float *i1, const float *im1, int nx,
                                         int ny, int pd, float *i0n, float *i1n)
 {
     int rc = preprocess_check(ctx, i0, i1, nx, ny, pd);
@@ -747,7 +848,13 @@ extern "C" int faldoi_preprocess_global(faldoi_ctx *ctx, const float *i0, const 
     return rc;
 }
 
-extern "C" int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
+extern "C" int faldoi_preprocess_global(faldoi_ctx *ctx, const float *i0, const float *i1, const float *im1, int nx,
+                                        int ny, int pd, float *i0n, float *i1n)
+{
+    return abi_guard("the preprocessing", [&] { return faldoi_preprocess_global_impl(ctx, i0, i1, im1, nx, ny, pd, i0n, i1n); });
+}
+
+static int faldoi_tvl1_batch_upload_images_impl(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
                                                const float *im1, int pd, const float *u, const float *xi)
 {
     if (!b || !u) return fail(FALDOI_ERR_INVALID, "NULL argument");
@@ -783,6 +890,12 @@ extern "C" int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, c
     return FALDOI_OK;
 }
 
+extern "C" int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
+                                               const float *im1, int pd, const float *u, const float *xi)
+{
+    return abi_guard("the batch upload", [&] { return faldoi_tvl1_batch_upload_images_impl(b, pair, i0, i1, im1, pd, u, xi); });
+}
+
 // ------------------------------------------------------------------------------------------ NLTV-CSAD
 // Host-side tables.  They involve pow/exp/hypot, whose last bit is a property of the C library; to
 // stay bit-identical with the reference they are evaluated here with the same libm calls the C++
@@ -802,7 +915,7 @@ extern "C" void faldoi_nltvcsad_default_params(faldoi_nltvcsad_params *p)
 static inline float sqf(float f) { return f * f; }      // aux_pow2, src/global_faldoi.cpp:904
 
 // src/global_faldoi.cpp:906-932
-extern "C" int faldoi_image_to_lab(const float *in, int nx, int ny, float *out)
+static int faldoi_image_to_lab_impl(const float *in, int nx, int ny, float *out)
 {
     if (!in || !out || nx < 1 || ny < 1) return fail(FALDOI_ERR_INVALID, "bad argument");
     const int size = nx * ny;
@@ -829,6 +942,11 @@ extern "C" int faldoi_image_to_lab(const float *in, int nx, int ny, float *out)
         out[i + 2 * size] = B * correct_lab;
     }
     return FALDOI_OK;
+}
+
+extern "C" int faldoi_image_to_lab(const float *in, int nx, int ny, float *out)
+{
+    return abi_guard("image_to_lab", [&] { return faldoi_image_to_lab_impl(in, nx, ny, out); });
 }
 
 // Weights of the 24 dual slots and their sum, src/global_faldoi.cpp:935-1054.  wts: [24][n], wt: [n].
@@ -867,10 +985,16 @@ static void nltv_weights_rows(const float *a, int pd, int w, int h, int y0, int 
 static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
                     int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms);
 
-extern "C" int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
+static int faldoi_nltvcsad_global_impl(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
                                       int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
 {
     return nl_solve(false, ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms);
+}
+
+extern "C" int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
+                                      int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
+{
+    return abi_guard("the NLTV-CSAD solver", [&] { return faldoi_nltvcsad_global_impl(ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms); });
 }
 
 extern "C" void faldoi_nltvl1_default_params(faldoi_nltvcsad_params *p)
@@ -880,10 +1004,16 @@ extern "C" void faldoi_nltvl1_default_params(faldoi_nltvcsad_params *p)
     p->lambda = 2.0f;      // src/global_faldoi.cpp:2146-2148: main overrides the -p file for -m 2/3
 }
 
-extern "C" int faldoi_nltvl1_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
+static int faldoi_nltvl1_global_impl(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
                                     int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
 {
     return nl_solve(true, ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms);
+}
+
+extern "C" int faldoi_nltvl1_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
+                                    int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
+{
+    return abi_guard("the NLTV-L1 solver", [&] { return faldoi_nltvl1_global_impl(ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms); });
 }
 
 static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
@@ -902,15 +1032,14 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
     // host tables (threads over row bands)
     std::vector<float> wts((size_t)kNlSlots * n), wt(n);
     {
-        unsigned nt = std::thread::hardware_concurrency();
-        nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
-        if ((unsigned)ny < nt) nt = (unsigned)ny;
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back(nltv_weights_rows, a, pd, nx, ny, (int)((long)ny * t / nt), (int)((long)ny * (t + 1) / nt),
-                            wts.data(), wt.data());
-        for (auto &t : th) t.join();
+        const int bands = ny < 64 ? ny : 64;
+        const bool ok = grow_host_parallel(bands, [&](int t) {
+            nltv_weights_rows(a, pd, nx, ny, (int)((long)ny * t / bands), (int)((long)ny * (t + 1) / bands), wts.data(),
+                              wt.data());
+        });
+        if (!ok) return fail(FALDOI_ERR_OOM, "out of host memory while building the NLTV weights");
     }
+    StreamDrain drain(s);                       // wts / wt are read by asynchronous copies below
 
     DevBuf buf;
     HIP_TRY(hipMalloc((void **)&buf.p, sizeof(float) * pe * N_COUNT));
@@ -977,7 +1106,7 @@ extern "C" void faldoi_local_tvl1_destroy(faldoi_local_tvl1 *h)
     delete h;
 }
 
-extern "C" int faldoi_local_tvl1_create(faldoi_ctx *ctx, const float *I0, const float *I1, int nx, int ny,
+static int faldoi_local_tvl1_create_impl(faldoi_ctx *ctx, const float *I0, const float *I1, int nx, int ny,
                                         faldoi_local_tvl1 **out)
 {
     if (!ctx || !I0 || !I1 || !out) return fail(FALDOI_ERR_INVALID, "NULL argument");
@@ -1010,6 +1139,12 @@ extern "C" int faldoi_local_tvl1_create(faldoi_ctx *ctx, const float *I0, const 
     }
     *out = h;
     return FALDOI_OK;
+}
+
+extern "C" int faldoi_local_tvl1_create(faldoi_ctx *ctx, const float *I0, const float *I1, int nx, int ny,
+                                        faldoi_local_tvl1 **out)
+{
+    return abi_guard("the local operator", [&] { return faldoi_local_tvl1_create_impl(ctx, I0, I1, nx, ny, out); });
 }
 
 extern "C" int faldoi_local_tvl1_set_flow(faldoi_local_tvl1 *h, const float *u)
@@ -1068,7 +1203,7 @@ extern "C" int faldoi_local_tvl1_set_fixed(faldoi_local_tvl1 *h, const int *fixe
     return FALDOI_OK;
 }
 
-extern "C" int faldoi_local_tvl1_interpolate(faldoi_local_tvl1 *h, int npatches, const int *patches)
+static int faldoi_local_tvl1_interpolate_impl(faldoi_local_tvl1 *h, int npatches, const int *patches)
 {
     if (!h || !patches) return fail(FALDOI_ERR_INVALID, "NULL argument");
     int rc = local_patches_to_device(h, npatches, patches);
@@ -1081,7 +1216,12 @@ extern "C" int faldoi_local_tvl1_interpolate(faldoi_local_tvl1 *h, int npatches,
     return FALDOI_OK;
 }
 
-extern "C" int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
+extern "C" int faldoi_local_tvl1_interpolate(faldoi_local_tvl1 *h, int npatches, const int *patches)
+{
+    return abi_guard("the window filling", [&] { return faldoi_local_tvl1_interpolate_impl(h, npatches, patches); });
+}
+
+static int faldoi_local_tvl1_estimate_impl(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
                                           float *ener_out, int *iters_out)
 {
     if (!h || !patches || !ener_out) return fail(FALDOI_ERR_INVALID, "NULL argument");
@@ -1098,8 +1238,14 @@ extern "C" int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, co
     return FALDOI_OK;
 }
 
+extern "C" int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
+                                          float *ener_out, int *iters_out)
+{
+    return abi_guard("the local operator", [&] { return faldoi_local_tvl1_estimate_impl(h, npatches, patches, max_iter_patch, ener_out, iters_out); });
+}
+
 // ------------------------------------------------------------------------------------------ self-test
-extern "C" int faldoi_selftest_division(faldoi_ctx *ctx, unsigned seed, unsigned long long count,
+static int faldoi_selftest_division_impl(faldoi_ctx *ctx, unsigned seed, unsigned long long count,
                                         unsigned long long *mismatches)
 {
     if (!ctx || !mismatches) return fail(FALDOI_ERR_INVALID, "NULL argument");
@@ -1135,6 +1281,12 @@ extern "C" int faldoi_selftest_division(faldoi_ctx *ctx, unsigned seed, unsigned
         fail(FALDOI_OK, "division selftest: %llu mismatches (dual site %llu, subnormal result %llu, divisor>1e30 %llu)",
              h[0], h[1], h[2], h[3]);
     return FALDOI_OK;
+}
+
+extern "C" int faldoi_selftest_division(faldoi_ctx *ctx, unsigned seed, unsigned long long count,
+                                        unsigned long long *mismatches)
+{
+    return abi_guard("the division self-test", [&] { return faldoi_selftest_division_impl(ctx, seed, count, mismatches); });
 }
 
 // ------------------------------------------------------------------------------------------ primitives

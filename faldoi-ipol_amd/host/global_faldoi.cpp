@@ -2,7 +2,7 @@
 // (src/global_faldoi.cpp:1846-2215) with the variational solve running on an MI355X through the
 // C ABI of libfaldoi_hip.so.
 //
-//   global_faldoi ims.txt in_flow.flo out.flo [-m method] [-w warps] [-p params.txt]
+//   global_faldoi ims.txt in_flow.flo out.flo [occl_input.png occl_out.png] [-m method] [-w warps] [-p params.txt]
 //                 [-glb_iters n] [-verbose 0|1]
 //   additive flags (defaults = reference behaviour):
 //                 [-max_inner n] [-tol_stop 0|1] [-chunk k] [-gpu id]
@@ -31,7 +31,10 @@ static int usage(size_t n)
     fprintf(stderr, "Without occlusions:\n");
     fprintf(stderr, "Usage: %zu  ims.txt in_flow.flo  out.flo [-m method_val] [-w num_warps] [-p file of parameters] "
                     "[-glb_iters global_iters] [-verbose verbose] \n", n);
-    fprintf(stderr, "  MI355X build extras: [-max_inner n] [-tol_stop 0|1] [-chunk k] [-gpu id]\n");
+    fprintf(stderr, "With occlusions:\n");
+    fprintf(stderr, "Usage: %zu  ims.txt in_flow.flo  out.flo occl_input.png occl_out.png [-m method_val] [-w num_warps] "
+                    "[-p file of parameters] [-glb_iters global_iters] [-verbose verbose]\n", n);
+    fprintf(stderr, "  MI355X build extras: [-max_inner n] [-tol_stop 0|1] [-chunk k] [-gpu id] [-print_params 1]\n");
     return EXIT_FAILURE;
 }
 
@@ -48,7 +51,10 @@ int main(int argc, char *argv[])
         const int tol_stop = std::stoi(pick_option(args, "tol_stop", "1"));
         const int chunk = std::stoi(pick_option(args, "chunk", "0"));
         const int gpu = std::stoi(pick_option(args, "gpu", "0"));
-        if (args.size() != 4) return usage(args.size());
+        const int print_params = std::stoi(pick_option(args, "print_params", "0"));   // additive: show what -p resolved to
+        // 3 or 5 positional arguments (:1865-1876).  The occlusion paths of the 5-argument form are only touched by
+        // method 8 in the reference (read :1944, written :2170-2180); for methods 0-7 they are accepted and ignored.
+        if (args.size() != 6 && args.size() != 4) return usage(args.size());
         const bool tvl1 = method == 0 || method == 1, nltvl1 = method == 2 || method == 3;
         const bool nltvcsad = method == 6 || method == 7, tvcsad = method == 4 || method == 5;
         if (!tvl1 && !nltvcsad && !nltvl1 && !tvcsad) {
@@ -83,6 +89,10 @@ int main(int argc, char *argv[])
         if (i0.pd == 2) { fprintf(stderr, "ERROR: two-channel images are not supported\n"); return EXIT_FAILURE; }
 
         const EnergyParams ep = read_energy_params(file_params);
+        if (print_params) {
+            printf("lambda %.9g theta %.9g tau %.9g tol %.9g\n", ep.lambda, ep.theta, ep.tau, ep.tol);
+            return EXIT_SUCCESS;
+        }
         faldoi_tvl1_params prm;
         faldoi_tvl1_default_params(&prm);
         prm.lambda = ep.lambda; prm.theta = ep.theta; prm.tau = ep.tau; prm.tol = ep.tol;

@@ -35,12 +35,14 @@ inline EnergyParams read_energy_params(const std::string &file)
     if (file.empty()) return p;
     std::ifstream in(file);
     std::string line;
-    auto next = [&]() { std::getline(in, line); return std::stof(line); };   // throws like the reference's stof
-    const float lambda = next(), theta = next(), tau = next();
-    if (lambda > 0) p.lambda = lambda;
-    if (theta > 0) p.theta = theta;
-    if (tau > 0 && tau <= 0.25f) p.tau = tau;
-    return p;
+    // all nine lines go through stof, which throws on a missing or malformed one exactly like the reference's
+    // init_params (an unreadable file gives an empty first line, hence std::invalid_argument there too)
+    float v[9];
+    for (float &x : v) { std::getline(in, line); x = std::stof(line); }
+    if (v[0] > 0) p.lambda = v[0];                       // :74-78
+    if (v[1] > 0) p.theta = v[1];                        // :83-87
+    if (v[2] > 0 && v[2] <= 0.25f) p.tau = v[2];         // :92-96 (0.25 is exact in both precisions)
+    return p;                                            // beta, alpha, tau_u, tau_eta, tau_chi, mu: occlusion model only
 }
 
 }  // namespace faldoi_host

@@ -22,3 +22,14 @@ def reduce_timing(local_seconds, local_units, dist=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), float(u.item())
+
+
+def gather_scalars(local_value, dist=None, device=None):
+    """Every rank's scalar, in rank order, on every rank (one all_gather of a 1-element tensor)."""
+    if dist is None or not dist.is_initialized():
+        return [float(local_value)]
+    import torch
+    t = torch.tensor([float(local_value)], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]

@@ -125,6 +125,10 @@ int faldoi_tvl1_batch_download(faldoi_tvl1_batch *b, int pair, float *u, float *
 int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *chunk_launches,
                                   long *px_iters, double *chunk_kernel_ms);
 
+/* Launch schedule the last batch_solve chose: tile = 64 columns x rows_per_thread*waves rows, `chunk` inner
+ * iterations per launch of the fused kernel (reporting only; results do not depend on it). */
+int faldoi_tvl1_batch_last_schedule(faldoi_tvl1_batch *b, int *rows_per_thread, int *waves, int *chunk);
+
 /* ---------------------------------------------------------------- primitives (host buffers)
  * Stand-alone launches of the device functions the fused kernel is made of, for stage-level
  * parity tests and for callers on either side of the hot path. */

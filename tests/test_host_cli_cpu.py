@@ -154,3 +154,41 @@ def test_faldoi_flow_cli_argument_handling(bins, tmp_path):
     if F.capi.lib().faldoi_device_count(ctypes.byref(n)) != 0:       # CI container: no GPU, no fallback
         r = subprocess.run([exe, str(ims), str(m), str(m), str(tmp_path / "o.flo")], capture_output=True, text=True)
         assert r.returncode == 3 and "no usable GPU" in r.stderr
+
+
+def test_global_faldoi_parameter_file_and_occlusion_argument_form(bins, tmp_path):
+    """-p params.txt as init_params reads it (src/utils_preprocess.cpp:65-155): nine lines lambda, theta, tau, beta, alpha,
+    tau_u, tau_eta, tau_chi, mu; a value <= 0 falls back to the default, tau > 0.25 too; a short or malformed file
+    makes stof throw.  The 5-positional form (occl_input occl_out, src/global_faldoi.cpp:1865-1876) is accepted for
+    methods 0-7, which never touch those two paths."""
+    exe = bins["global_faldoi"]
+    ims = tmp_path / "ims.txt"
+    ims.write_text(os.path.join(GOLDEN, "sintel_clean_easy_frame_0002.png") + "\n"
+                   + os.path.join(GOLDEN, "sintel_clean_easy_frame_0003.png") + "\n")
+    z = tmp_path / "zero.flo"
+    F.flo.write_flo(str(z), np.zeros((2, 436, 1024), np.float32))
+    o = str(tmp_path / "o.flo")
+
+    def resolved(text, extra=()):
+        pf = tmp_path / "params.txt"
+        pf.write_text(text)
+        return subprocess.run([exe, str(ims), str(z), o, "-p", str(pf), "-print_params", "1", *extra],
+                              capture_output=True, text=True)
+
+    nine = "35\n0.25\n0.2\n1\n1\n0.1\n0.1\n0.1\n1\n"
+    r = resolved(nine)
+    assert r.returncode == 0 and r.stdout.split() == ["lambda", "35", "theta", "0.25", "tau", "0.200000003", "tol", "0.00999999978"]
+    r = resolved("-1\n0\n0.3\n1\n1\n0.1\n0.1\n0.1\n1\n")            # <= 0 -> default; tau > 0.25 -> default
+    assert r.returncode == 0 and r.stdout.split() == ["lambda", "40", "theta", "0.300000012", "tau", "0.125", "tol", "0.00999999978"]
+    r = resolved("35\n0.25\n0.25\n1\n1\n0.1\n0.1\n0.1\n1\n")         # tau == 0.25 is kept
+    assert r.returncode == 0 and r.stdout.split()[5] == "0.25"
+    r = resolved("35\n0.25\n0.2\n")                                   # three lines: the reference's stof("") throws
+    assert r.returncode == 1 and "stof" in r.stderr
+    r = resolved("forty\n" + nine)
+    assert r.returncode == 1
+    # occlusion form: five positional arguments, options anywhere
+    r = subprocess.run([exe, str(ims), "-m", "0", str(z), o, str(tmp_path / "occ_in.png"), str(tmp_path / "occ_out.png"),
+                        "-print_params", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("lambda 40 ")
+    r = subprocess.run([exe, str(ims), str(z), o, "one_too_many"], capture_output=True, text=True)
+    assert r.returncode == 1 and "With occlusions" in r.stderr

@@ -106,3 +106,51 @@ def test_batch_job_file_parsing(tmp_path):
     with pytest.raises(ValueError):
         F.batch.parse_jobs(str(f))
     assert F.batch.shard_sizes(5, 2) == [[0, 2, 4], [1, 3]]
+
+
+def test_bench_gpus_n_starts_n_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` as ONE plain process must start two ranks under torch.distributed.run (before
+    anything touches a GPU), reduce over them and print one JSON line with n_gpus 2 (launcher self-test: gloo, stub
+    step).  A WORLD_SIZE that disagrees with --gpus is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0",
+                        "--pairs-per-gpu", "4", "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and len(out["per_rank"]) == 2
+    assert out["units"] == 2 * 3 * 4                       # SUM over ranks of steps x pairs per GPU
+    assert out["seconds_max"] >= 3 * 0.02 * 0.9            # MAX over ranks: rank 1 sleeps twice as long
+    env["WORLD_SIZE"] = "3"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_batch_load_jobs_rejects_mismatched_inputs(tmp_path):
+    """load_jobs (rank 0 of batch.py) raises on unreadable or mismatched inputs; main() turns that into an error
+    marker broadcast to every rank instead of leaving them in the collective."""
+    import numpy as np
+    from PIL import Image
+    a, b = tmp_path / "a.png", tmp_path / "b.png"
+    Image.fromarray(np.zeros((6, 8, 3), np.uint8)).save(a)
+    Image.fromarray(np.zeros((6, 9, 3), np.uint8)).save(b)
+    jobs = tmp_path / "jobs.txt"
+    jobs.write_text("%s %s zero o.flo\n" % (a, b))
+    with pytest.raises(ValueError):
+        F.batch.load_jobs(str(jobs), F)
+    jobs.write_text("%s %s zero o.flo\n" % (a, tmp_path / "missing.png"))
+    with pytest.raises(OSError):
+        F.batch.load_jobs(str(jobs), F)
+    F.flo.write_flo(str(tmp_path / "f.flo"), np.zeros((2, 5, 8), np.float32))
+    jobs.write_text("%s %s %s o.flo\n" % (a, a, tmp_path / "f.flo"))
+    with pytest.raises(ValueError):
+        F.batch.load_jobs(str(jobs), F)
+    jobs.write_text("%s %s zero o.flo\n" % (a, a))
+    j, fr, fl = F.batch.load_jobs(str(jobs), F)
+    assert fr.shape == (1, 2, 3, 6, 8) and fl.shape == (1, 2, 6, 8)
