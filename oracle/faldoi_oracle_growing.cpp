@@ -13,6 +13,7 @@
 // PARITY UNPINNED at this level: src/local_faldoi.cpp includes <boost/lexical_cast.hpp>, which
 // this image lacks, so the orchestration cannot be compiled from the reference here, and the
 // seed-dependent known answers of SURVEY App. D need the matcher binaries (not runnable here).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -360,6 +361,101 @@ void prune_and_reseed(Direction *d, int w, int h, float fb_thresh)       // :123
 }
 
 }  // namespace
+
+// ---- test hooks for the partition bookkeeping (tests/test_oracle_cpu.py pins them against the reference's own
+// init_subimage_partitions / image_to_partitions objects through oracle/_ref): an image-level state whose planes the
+// test sets, one partition grid, transfers in both directions.  Plane ids: 0 u1, 1 u2, 2..5 xi11 xi12 xi21 xi22,
+// 6 div_xi1, 7 div_xi2, 8 I1x, 9 I1y, 10 ene, 11 / 12 out flow u / v, 13 fixed, 14 trust (ints as floats).
+namespace {
+struct PartsHook {
+    std::vector<float> i0n, i1n;
+    Direction d[2];
+    std::vector<Partition> P;
+};
+float *hook_plane(Direction &d, int id, int **ip)
+{
+    const size_t n = (size_t)d.w * d.h;
+    *ip = NULL;
+    if (id <= 1) return d.u.data() + id * n;
+    if (id <= 7) return d.state.data() + (size_t)(id - 2) * n;
+    if (id == 8) return d.dstx.data();
+    if (id == 9) return d.dsty.data();
+    if (id == 10) return d.ene.data();
+    if (id <= 12) return d.out.data() + (size_t)(id - 11) * n;
+    *ip = id == 13 ? d.fixed.data() : d.trust.data();
+    return NULL;
+}
+void hook_copy(Direction &d, int id, float *v, bool set)
+{
+    int *ip;
+    float *p = hook_plane(d, id, &ip);
+    const size_t n = (size_t)d.w * d.h;
+    for (size_t i = 0; i < n; i++) {
+        if (set) { if (p) p[i] = v[i]; else ip[i] = (int)v[i]; }
+        else v[i] = p ? p[i] : (float)ip[i];
+    }
+}
+}  // namespace
+
+extern "C" void *orc_parts_create(const float *i0n, const float *i1n, int w, int h, int cols, int rows, int wr)
+{
+    PartsHook *r = new PartsHook();
+    r->i0n.assign(i0n, i0n + (size_t)w * h);
+    r->i1n.assign(i1n, i1n + (size_t)w * h);
+    init_direction(r->d[0], r->i0n.data(), r->i1n.data(), NULL, w, h, wr, 4, 0);
+    init_direction(r->d[1], r->i1n.data(), r->i0n.data(), NULL, w, h, wr, 4, 0);
+    for (int k = 0; k < 2; k++) {                       // the arrays of prepare_data_for_growing, src/local_faldoi.cpp:860-870
+        std::fill(r->d[k].ene.begin(), r->d[k].ene.end(), INFINITY);
+        std::fill(r->d[k].out.begin(), r->d[k].out.end(), NAN);
+        std::fill(r->d[k].trust.begin(), r->d[k].trust.end(), 0);
+    }
+    make_partitions(r->P, cols, rows, r->d);
+    return r;
+}
+extern "C" void orc_parts_destroy(void *h) { delete (PartsHook *)h; }
+extern "C" int orc_parts_count(void *h) { return (int)((PartsHook *)h)->P.size(); }
+extern "C" void orc_parts_geometry(void *h, int p, int *geom)
+{
+    const Partition &q = ((PartsHook *)h)->P[p];
+    geom[0] = q.w; geom[1] = q.h; geom[2] = q.ox; geom[3] = q.oy;
+}
+extern "C" void orc_parts_set_image_plane(void *h, int dir, int id, const float *v)
+{ hook_copy(((PartsHook *)h)->d[dir], id, const_cast<float *>(v), true); }
+extern "C" void orc_parts_get_image_plane(void *h, int dir, int id, float *v) { hook_copy(((PartsHook *)h)->d[dir], id, v, false); }
+extern "C" void orc_parts_set_part_plane(void *h, int part, int dir, int id, const float *v)
+{ hook_copy(((PartsHook *)h)->P[part].d[dir], id, const_cast<float *>(v), true); }
+extern "C" void orc_parts_get_part_plane(void *h, int part, int dir, int id, float *v)
+{ hook_copy(((PartsHook *)h)->P[part].d[dir], id, v, false); }
+extern "C" void orc_parts_get_part_frame(void *h, int part, int which, float *v)
+{
+    const Direction &d = ((PartsHook *)h)->P[part].d[0];             // forward: src = i0n crop, dst = i1n crop
+    const std::vector<float> &f = which ? d.own_dst : d.own_src;
+    memcpy(v, f.data(), sizeof(float) * f.size());
+}
+extern "C" void orc_parts_push(void *h, int dir, int i, int j, float u, float v, float sim)
+{
+    Candidate c = { i, j, u, v, sim };
+    ((PartsHook *)h)->d[dir].queue.push(c);
+}
+extern "C" int orc_parts_image_queue_size(void *h, int dir) { return (int)((PartsHook *)h)->d[dir].queue.size(); }
+extern "C" void orc_parts_transfer(void *h, int img_to_part)
+{
+    PartsHook *r = (PartsHook *)h;
+    image_to_partitions(r->P, r->d, img_to_part != 0);
+}
+extern "C" int orc_parts_any_empty(void *h) { return any_empty_queues(((PartsHook *)h)->P) ? 1 : 0; }
+extern "C" int orc_parts_drain_queue(void *h, int part, int dir, float *out, int cap)
+{
+    CandidateQueue &q = ((PartsHook *)h)->P[part].d[dir].queue;
+    int k = 0;
+    while (!q.empty() && k < cap) {
+        const Candidate c = q.top();
+        q.pop();
+        out[5 * k] = (float)c.i; out[5 * k + 1] = (float)c.j; out[5 * k + 2] = c.u; out[5 * k + 3] = c.v; out[5 * k + 4] = c.sim;
+        k++;
+    }
+    return k;
+}
 
 /* split_img = 0: whole-image growings.  split_img = 1 (-split_img 1 -h_parts H -v_parts V): local iteration 0 on the
  * whole image, odd iterations on an H x V grid of partitions, even ones on a V x H grid, the last growing on the H x V

@@ -70,13 +70,16 @@ float orc_local_tvl1_estimate(const float *I0, const float *I1, const float *I1x
     return local_estimate(I0, I1, I1x, I1y, u1, u2, st, nx, ny, ii, ij, ei, ej, max_iter_patch, iters_out, NULL, 0, 0, 40);
 }
 
-/* gaussian1Dweight, src/utils.cpp:633-651 (C++: exp of a float argument is expf) */
+/* gaussian1Dweight as prepare_stuff calls it (src/energy_model.cpp:432-435): src/mask.c:360-372, the C-linkage copy --
+ * energy_model.cpp includes mask.h inside extern "C" before utils.h (:18-23), so the name binds to the C function, where
+ * exp() is the double function (the C++ copy, src/utils.cpp:633, would call expf: some weights differ in the last bit).
+ * -(i-r)*(i-r) is an int, the quotient by `den` a float, exp and the product run in double, one rounding to float. */
 void orc_gaussian1d_weight(float *I, int r)
 {
     const float sigma = r * 0.3333;
     const float den = 2 * sigma * sigma;
     for (int i = 0; i < 2 * r + 1; i++)
-        I[i] = (float)(1 / (sigma * sqrt(2.0 * 3.1415926)) * expf(-(i - r) * (i - r) / den));
+        I[i] = (float)(1 / (sigma * sqrt(2.0 * 3.1415926)) * exp((double)(-(i - r) * (i - r) / den)));
 }
 
 /* The weighted functional (-m 1): of_estimation's M_TVL1_W branch (src/energy_model.cpp:742-749) =

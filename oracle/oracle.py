@@ -114,6 +114,10 @@ def lib():
         L.orc_queue_free.argtypes = [C.c_void_p]
         L.orc_queue_push.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
         L.orc_queue_pop.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_float)] * 3
+        L.orc_parts_create.restype = C.c_void_p
+        L.orc_parts_create.argtypes = [_F, _F] + [C.c_int] * 5
+        L.orc_parts_destroy.argtypes = [C.c_void_p]
+        _bind_parts(L, "orc_parts_")
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads(cpu_share())      # libgomp may already be loaded (torch) with its own default
@@ -154,13 +158,180 @@ def ref():
                 R.ref_local_tvl1w_estimate.restype = C.c_float
                 R.ref_local_tvl1w_estimate.argtypes = [C.c_void_p, _F, _F, _F, _F, _F, _F] + [C.c_int] * 8
                 R.ref_gaussian1d_weight.argtypes = [_F, C.c_int]
+                if hasattr(R, "ref_local_tvl1w_set_weight"):
+                    R.ref_local_tvl1w_set_weight.argtypes = [C.c_void_p, _F]
             R.ref_elap_recursive_separable.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
         if hasattr(R, "ref_zoom_out"):
             R.ref_zoom_size.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_float]
             R.ref_zoom_out.argtypes = [_F, _F, C.c_int, C.c_int, C.c_float]
             R.ref_zoom_in.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
+        if hasattr(R, "ref_op_create"):                         # ref_harness_models.cpp
+            vp = C.c_void_p
+            R.ref_op_create.restype = vp
+            R.ref_op_create.argtypes = [C.c_int] * 5
+            R.ref_op_prepare.argtypes = [vp, _F, _F, C.c_int, _F, _F]
+            R.ref_op_set_flow.argtypes = [vp, C.c_int, _F]
+            R.ref_op_get_flow.argtypes = [vp, C.c_int, _F]
+            R.ref_op_estimate.restype = C.c_float
+            R.ref_op_estimate.argtypes = [vp] + [C.c_int] * 10
+            R.ref_op_plane.argtypes = [vp, C.c_int, C.c_char_p, _F]
+            R.ref_op_duals.argtypes = [vp, C.c_int, C.c_int, _F, _F, _F]
+            R.ref_op_destroy.argtypes = [vp]
+            R.ref_rgb_to_lab.argtypes = [_F, C.c_int, _F]
+            R.ref_nltv_table.argtypes = [_F, C.c_int, C.c_int, C.c_int, _F, _F, _I, _I, _I, _F]
+            R.ref_csad_table.argtypes = [C.c_int, C.c_int, _I, _I, _I]
+            R.ref_gaussian1d_weight_c.argtypes = [_F, C.c_int]
+            R.ref_op_weight.argtypes = [vp, C.c_int, _F]
+            R.ref_parts_create.restype = vp
+            R.ref_parts_create.argtypes = [_F, _F, C.c_int, _F, _F] + [C.c_int] * 5
+            _bind_parts(R, "ref_parts_")
         _ref = R
     return _ref
+
+
+def _bind_parts(L, prefix):
+    """The partition hooks have one signature set on both sides (oracle: orc_parts_*, reference: ref_parts_*)."""
+    vp = C.c_void_p
+    g = lambda name: getattr(L, prefix + name)
+    g("count").argtypes = [vp]
+    g("geometry").argtypes = [vp, C.c_int, _I]
+    g("set_image_plane").argtypes = [vp, C.c_int, C.c_int, _F]
+    g("get_image_plane").argtypes = [vp, C.c_int, C.c_int, _F]
+    g("set_part_plane").argtypes = [vp, C.c_int, C.c_int, C.c_int, _F]
+    g("get_part_plane").argtypes = [vp, C.c_int, C.c_int, C.c_int, _F]
+    g("get_part_frame").argtypes = [vp, C.c_int, C.c_int, _F]
+    g("push").argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    g("image_queue_size").argtypes = [vp, C.c_int]
+    g("transfer").argtypes = [vp, C.c_int]
+    g("any_empty").argtypes = [vp]
+    g("drain_queue").argtypes = [vp, C.c_int, C.c_int, _F, C.c_int]
+
+
+class Parts:
+    """One partition grid over an image-level state, on the oracle (side="orc") or the reference (side="ref")."""
+
+    def __init__(self, side, i0, i1, i0n, i1n, cols, rows, wr=5):
+        self.side = side
+        i0, i1, i0n, i1n = f32(i0), f32(i1), f32(i0n), f32(i1n)
+        self.h, self.w = i0n.shape
+        if side == "ref":
+            self.L, self.pre = ref(), "ref_parts_"
+            self._h = self.L.ref_parts_create(i0, i1, i0.shape[0], i0n, i1n, self.w, self.h, cols, rows, wr)
+        else:
+            self.L, self.pre = lib(), "orc_parts_"
+            self._h = self.L.orc_parts_create(i0n, i1n, self.w, self.h, cols, rows, wr)
+
+    def _f(self, name):
+        return getattr(self.L, self.pre + name)
+
+    def count(self):
+        return self._f("count")(self._h)
+
+    def geometry(self, p):
+        g = np.zeros(4, np.int32)
+        self._f("geometry")(self._h, p, g)
+        return tuple(int(x) for x in g)            # width, height, off_x, off_y
+
+    def set_image(self, d, pid, v):
+        self._f("set_image_plane")(self._h, d, pid, f32(v))
+
+    def get_image(self, d, pid):
+        v = np.empty((self.h, self.w), np.float32)
+        self._f("get_image_plane")(self._h, d, pid, v)
+        return v
+
+    def set_part(self, p, d, pid, v):
+        self._f("set_part_plane")(self._h, p, d, pid, f32(v))
+
+    def get_part(self, p, d, pid):
+        w, h, _, _ = self.geometry(p)
+        v = np.empty((h, w), np.float32)
+        self._f("get_part_plane")(self._h, p, d, pid, v)
+        return v
+
+    def part_frame(self, p, which):
+        w, h, _, _ = self.geometry(p)
+        v = np.empty((h, w), np.float32)
+        self._f("get_part_frame")(self._h, p, which, v)
+        return v
+
+    def push(self, d, i, j, u, v, sim):
+        self._f("push")(self._h, d, int(i), int(j), float(u), float(v), float(sim))
+
+    def image_queue_size(self, d):
+        return self._f("image_queue_size")(self._h, d)
+
+    def transfer(self, img_to_part):
+        self._f("transfer")(self._h, int(bool(img_to_part)))
+
+    def any_empty(self):
+        return bool(self._f("any_empty")(self._h))
+
+    def drain(self, p, d, cap=1 << 16):
+        out = np.empty((cap, 5), np.float32)
+        k = self._f("drain_queue")(self._h, p, d, out, cap)
+        return out[:k].copy()
+
+
+def ref_weighted_operator(w, h, wr=5):
+    """The reference's weighted window operator (src/tvl2w_model.cpp) with the window weights prepare_stuff gives it
+    (gaussian1Dweight of src/mask.c).  Returns the handle for ref_local_tvl1w_estimate / _destroy."""
+    R = ref()
+    hnd = R.ref_local_tvl1w_create(w, h, wr)
+    wv = np.zeros(2 * wr + 1, np.float32)
+    R.ref_gaussian1d_weight_c(wv, wr)
+    R.ref_local_tvl1w_set_weight(hnd, wv)
+    return hnd
+
+
+class RefOp:
+    """The reference's operator surface of the local step (initialize_auxiliar_stuff / prepare_stuff / of_estimation,
+    src/energy_model.cpp) for functional `method`, forward (0) and backward (1) direction."""
+
+    def __init__(self, method, w, h, wr=5, max_iter_patch=4):
+        self.R = ref()
+        self.method, self.w, self.h, self.wr = method, w, h, wr
+        self._h = self.R.ref_op_create(method, w, h, wr, max_iter_patch)
+
+    def prepare(self, i0, i1):
+        i0, i1 = f32(i0), f32(i1)
+        pd = 1 if i0.ndim == 2 else i0.shape[0]
+        a, b = np.empty((self.h, self.w), np.float32), np.empty((self.h, self.w), np.float32)
+        self.R.ref_op_prepare(self._h, i0, i1, pd, a, b)
+        return a, b
+
+    def set_flow(self, d, u):
+        self.R.ref_op_set_flow(self._h, d, f32(u))
+
+    def get_flow(self, d):
+        u = np.empty((2, self.h, self.w), np.float32)
+        self.R.ref_op_get_flow(self._h, d, u)
+        return u
+
+    def estimate(self, d, i, j, wr_call):
+        ii, ij, ei, ej = patch_index(wr_call, self.w, self.h, i, j)
+        iiw = -(i - wr_call) if i - wr_call < 0 else 0          # get_relative_index_weight, src/local_faldoi.cpp:548-558
+        ijw = -(j - wr_call) if j - wr_call < 0 else 0
+        return float(np.float32(self.R.ref_op_estimate(self._h, d, i, j, ii, ij, ei, ej, wr_call, iiw, ijw)))
+
+    def plane(self, d, name):
+        v = np.empty((self.h, self.w), np.float32)
+        if self.R.ref_op_plane(self._h, d, name.encode(), v) != 0:
+            raise KeyError(name)
+        return v
+
+    def duals(self, d, which=0):
+        sc = np.empty((24, self.h, self.w), np.float32)
+        wp = np.empty_like(sc)
+        wt = np.empty((self.h, self.w), np.float32)
+        if self.R.ref_op_duals(self._h, d, which, sc, wp, wt) != 0:
+            raise KeyError("no dual tables for method %d" % self.method)
+        return sc, wp, wt
+
+    def close(self):
+        if self._h:
+            self.R.ref_op_destroy(self._h)
+            self._h = None
 
 
 # ---------------------------------------------------------------- convenience wrappers

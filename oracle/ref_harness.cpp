@@ -119,7 +119,7 @@ struct RefLocalW {
     int w, h, wr;
 };
 
-void ref_gaussian1d_weight(float *I, int r) { gaussian1Dweight(I, r); }
+void ref_gaussian1d_weight(float *I, int r) { gaussian1Dweight(I, r); }     // the C++ copy, src/utils.cpp:633 (NOT what prepare_stuff binds)
 
 void *ref_local_tvl1w_create(int w, int h, int wr)
 {
@@ -132,8 +132,17 @@ void *ref_local_tvl1w_create(int w, int h, int wr)
     float *planes[] = {t.xi11, t.xi12, t.xi21, t.xi22, t.u1x, t.u1y, t.u2x, t.u2y, t.v1, t.v2, t.rho_c, t.grad,
                        t.u1_, t.u2_, t.u1Aux, t.u2Aux, t.I1x, t.I1y, t.I1w, t.I1wx, t.I1wy, t.div_xi1, t.div_xi2, t.u_N};
     for (float *p : planes) memset(p, 0, sizeof(float) * (size_t)w * h);
-    gaussian1Dweight(t.weight, wr);                                  // prepare_stuff, src/energy_model.cpp:432-435
+    // prepare_stuff (src/energy_model.cpp:432-435) fills t.weight with gaussian1Dweight -- the C-linkage copy of src/mask.c,
+    // which this translation unit cannot name next to utils.h's C++ declaration: the caller passes those weights in
+    // (ref_gaussian1d_weight_c of ref_harness_models.cpp) through ref_local_tvl1w_set_weight.
+    memset(t.weight, 0, sizeof(float) * (2 * wr + 1));
     return r;
+}
+
+void ref_local_tvl1w_set_weight(void *h, const float *weight)
+{
+    RefLocalW *r = (RefLocalW *)h;
+    memcpy(r->stuff.tvl2w.weight, weight, sizeof(float) * (2 * r->wr + 1));
 }
 
 void ref_local_tvl1w_destroy(void *h)

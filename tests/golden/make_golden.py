@@ -105,7 +105,7 @@ def main():
     out["loc_u0"] = u0
     for tag in ("plain", "weighted"):
         u = u0.copy()
-        ref = R.ref_local_tvl1w_create(lw, lh, 5) if tag == "weighted" else R.ref_local_tvl1_create(lw, lh)
+        ref = O.ref_weighted_operator(lw, lh, 5) if tag == "weighted" else R.ref_local_tvl1_create(lw, lh)
         eners = []
         for ci, cj, wc in wins:
             ii, ij, ei, ej = O.patch_index(int(wc), lw, lh, int(ci), int(cj))
@@ -119,7 +119,7 @@ def main():
         out["loc_u_" + tag], out["loc_e_" + tag] = u, np.array(eners, np.float32)
     for r in (1, 3, 5):
         wv = np.zeros(2 * r + 1, np.float32)
-        R.ref_gaussian1d_weight(wv, r)
+        R.ref_gaussian1d_weight_c(wv, r)            # src/mask.c:360, the copy prepare_stuff binds
         out["gw_%d" % r] = wv
     np.savez_compressed(os.path.join(HERE, "ref_primitives.npz"), **out)
     print("wrote ref_primitives.npz with", len(out), "arrays")
