@@ -916,3 +916,87 @@ def test_match_growing_partitions_fall_back_to_the_whole_image(ctx, oracle):
     assert bits_equal(got, want), mismatch_report(got, want)
     plain, _, _ = oracle.local_faldoi(a, b, go, none)
     assert bits_equal(plain, want)                          # with the fall-back it is the unpartitioned run
+
+
+# ------------------------------------------------------------------ BASELINE configs at their own size
+def test_full_size_pipeline_final_hard_reference_defaults(ctx, oracle, tmp_path):
+    """BASELINE configs[2]: the whole chain on the Sintel final/hard example pair at 1024x436 with the reference's
+    defaults (-m 0 -wr 5 -loc_it 3 -max_pch_it 4 -split_img 0 -fb_thresh 2, then global -w 5): `faldoi_flow` from match
+    lists; the local flow, the energy map and the final flow are bit-identical to the CPU checker's.  (Slow: the two
+    whole-image growings are sequential on both sides.  The matcher binaries cannot run here, so the match lists are
+    ~1.1 % of a dense TV-L1 flow rounded to integers.)"""
+    import os
+    import time
+    from util import GOLDEN, load_rgb_planar
+    bins = F.build.build_host()
+    f2 = os.path.join(GOLDEN, "sintel_final_hard_frame_0002.png")
+    f3 = os.path.join(GOLDEN, "sintel_final_hard_frame_0003.png")
+    i0, i1 = load_rgb_planar(f2), load_rgb_planar(f3)
+    h, w = i0.shape[1:]
+    assert (w, h) == (1024, 436)
+    a, b = ctx.preprocess_local(i0, i1)
+    oa, ob = oracle.preprocess_local(i0, i1)
+    assert bits_equal(a, oa) and bits_equal(b, ob)
+    rng = np.random.default_rng(1)
+    for name, (src, dst) in (("m0.txt", (a, b)), ("m1.txt", (b, a))):
+        u = ctx.tvl1_global(src, dst, np.zeros((2, h, w), np.float32), warps=5)[0]
+        ys, xs = np.nonzero(rng.random((h, w)) < 0.011)
+        with open(tmp_path / name, "w") as f:
+            for y, x in zip(ys, xs):
+                f.write("%d %d %d %d\n" % (x, y, x + int(round(float(u[0, y, x]))), y + int(round(float(u[1, y, x])))))
+    (tmp_path / "ims.txt").write_text(f2 + "\n" + f3 + "\n")
+    t0 = time.time()
+    r = subprocess.run([bins["faldoi_flow"], str(tmp_path / "ims.txt"), str(tmp_path / "m0.txt"), str(tmp_path / "m1.txt"),
+                        str(tmp_path / "out.flo"), "-matcher", "cut", "-local_out", str(tmp_path / "local.flo"), "-sim_out",
+                        str(tmp_path / "sim.pgm"), "-verbose", "1"], capture_output=True, text=True)
+    gpu_s = time.time() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    for m, o in (("m0.txt", "s0.flo"), ("m1.txt", "s1.flo")):
+        rr = subprocess.run([bins["sparse_flow"], str(tmp_path / m), str(w), str(h), str(tmp_path / o)], capture_output=True, text=True)
+        assert rr.returncode == 0, rr.stderr
+    go, ba = F.flo.read_flo(str(tmp_path / "s0.flo")), F.flo.read_flo(str(tmp_path / "s1.flo"))
+    assert np.isfinite(go[0]).sum() > 4000 and np.isfinite(ba[0]).sum() > 4000
+    t0 = time.time()
+    want_local, want_ene, st = oracle.local_faldoi(oa, ob, go, ba)
+    cpu_s = time.time() - t0
+    got_local = F.flo.read_flo(str(tmp_path / "local.flo"))
+    assert bits_equal(got_local, want_local), mismatch_report(got_local, want_local)
+    sim = open(tmp_path / "sim.pgm").read().split()
+    assert sim[:4] == ["P2", str(w), str(h), "65535"]
+    got_ene = np.array([float.fromhex(v) for v in sim[4:]], np.float32)
+    assert bits_equal(got_ene.reshape(h, w), want_ene)
+    g0, g1 = oracle.preprocess_global(i0, i1, None)
+    u = want_local.copy()
+    xi = np.zeros((4, h, w), np.float32)
+    its, errs = np.zeros(5, np.int32), np.zeros(5, np.float32)
+    oracle.lib().orc_tvl1_global(g0, g1.copy(), u[0], u[1], xi[0], xi[1], xi[2], xi[3], 40, 0.3, 0.125, 0.01, w, h, 5, 400, 1, its, errs)
+    got = F.flo.read_flo(str(tmp_path / "out.flo"))
+    assert float(F.flo.epe(got, u).mean()) <= EPE_GATE
+    assert bits_equal(got, u), mismatch_report(got, u)
+    print("configs[2] 1024x436 -split_img 0: faldoi_flow %.1f s wall (%s); CPU checker local step %.1f s on 2 threads; "
+          "%d windows" % (gpu_s, "; ".join(l for l in r.stdout.splitlines() if l.startswith("faldoi_flow")), cpu_s, st[1] + st[4]))
+
+
+def test_nltvcsad_full_size_bounded_schedule_and_determinism(ctx, oracle):
+    """BASELINE configs[4] at its own size (Sintel clean/easy 1024x436, -m 6): a bounded schedule (1 warp x 40 iterations)
+    bit-identical to the CPU checker, and the full 1 x 400 schedule twice with identical bits (no atomics, no
+    order-dependent reduction anywhere in the two streaming kernels)."""
+    i0, i1 = sintel_pair()
+    h, w = i0.shape[1:]
+    assert (w, h) == (1024, 436)
+    i0n, i1n = ctx.preprocess_global(i0, i1)
+    lab = F.capi.image_to_lab(i0)
+    assert bits_equal(lab, oracle.image_to_lab(i0))
+    u0 = np.zeros((2, h, w), np.float32)
+    u, _ = ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=40)
+    ou = oracle.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=40)
+    assert float(F.flo.epe(u, ou).mean()) <= EPE_GATE
+    assert bits_equal(u, ou), mismatch_report(u, ou)
+    ua, ms_a = ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=400)
+    ub, ms_b = ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=1, max_inner=400)
+    assert bits_equal(ua, ub) and np.isfinite(ua).all()
+    # a warm-started second warp continues from the first: 2 x 20 equals nothing else than itself twice, and differs from 1 x 40
+    uc, _ = ctx.nltvcsad_global(i0n, i1n, lab, u0, warps=2, max_inner=20)
+    oc = oracle.nltvcsad_global(i0n, i1n, lab, u0, warps=2, max_inner=20)
+    assert bits_equal(uc, oc), mismatch_report(uc, oc)
+    print("configs[4] 1024x436: 1 x 400 iterations %.1f / %.1f ms on the device" % (ms_a, ms_b))
