@@ -23,11 +23,12 @@ WARPS, INNER = 300, 10
 BYTES_PER_PX_ITER = 76        # 19 fp32 planes touched once per inner iteration
 BYTES_PER_PX_WARP = 44        # per outer warp (bicubic gathers + constants)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# NLTV-CSAD as built, fp32 planes touched per pixel-iteration by the two streaming kernels:
+# NLTV-CSAD as built, fp32 planes touched per pixel-iteration by the two streaming kernels
+# (neighbours' values are re-reads of planes counted once):
 #   nl_dual_kernel   reads p,q (48) + w (24) + wt + ubar1,ubar2 = 75, writes p,q (48)
-#   nl_primal_kernel reads p,q (48) + w (24) + wt + u1,u2,ubar.. (4) + I0,I1w,I1wx,I1wy,grad (5) + 2 warp products = 84,
+#   nl_primal_kernel reads p,q (48) + w (24) + wt + u1,u2 + I0,I1w,I1wx,I1wy,grad + the 2 warp-start products = 82,
 #                    writes u1,u2,ubar1,ubar2 (4)
-NLTV_BYTES_PER_PX_ITER = 4 * (75 + 48 + 84 + 4)
+NLTV_BYTES_PER_PX_ITER = 4 * (75 + 48 + 82 + 4)
 VALU_PEAK_GINSTR = 1024 * 0.5 * 2.4   # 256 CUs x 4 SIMD-32 x one wave64 VALU instruction per 2 clk x 2.4 GHz (MI355X_MICROARCH.md)
 # rocprofv3 counter summaries of the kernels (per launch), written by tools/pmc_summary.py from the PMC passes
 # of the SAME bench command; nothing here is typed in by hand
@@ -352,7 +353,7 @@ def nltvcsad_leg(out, F, np, ctx, pairs, rgb0):
            "deterministic_two_runs": bool(np.array_equal(ua.view(np.uint32), ub.view(np.uint32))),
            "note": "two streaming launches per iteration; bytes per pixel-iteration of the layout actually built "
                    "(DESIGN.md 3.4): dual kernel r 48 p,q + 24 w + wt + ub(2) / w 48; primal kernel r 48 + 24 + wt + "
-                   "u,ub(4) + I0,I1w,Ix,Iy,g + 2 warp products / w 4"}
+                   "u(2) + I0,I1w,Ix,Iy,g + 2 warp products / w 4 = 209 planes x 4 B"}
     for k in ("nl_primal_kernel", "nl_dual_kernel"):
         if k in cnt and "FETCH_SIZE_KB" in cnt[k]:
             leg[k] = {"avg_us": cnt[k].get("avg_us"),

@@ -518,7 +518,7 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
                 }
                 if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
                 HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
-                                     b->ctl, b->err_part, 1, cur, n == 0, it, w));
+                                     b->ctl, b->err_part, 1, cur, (n == 0 ? 1 : 0) | (n + it >= prm->max_inner ? 2 : 0), it, w));
                 if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
                 ++launches;
                 cur ^= 1;

@@ -292,7 +292,7 @@ template <int R, int NW, bool BORDER>
 __device__ __forceinline__ void tvl1_chunk_body(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int npairs, int ntiles, int t,
     int pair, int txi, int tyi, int halo, const TvConst &prm, float *__restrict__ err_out,
-    int cur, int first, int iters, int err_slot,
+    int cur, int first /* bit 0: starts a warp, bit 1: ends one */, int iters, int err_slot,
     float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW], float (*s_x22)[kTileW],
     unsigned (*s_err)[kTileW])
 {
@@ -336,6 +336,8 @@ __device__ __forceinline__ void tvl1_chunk_body(
         gr[r] = grad_sq(ix[r], iy[r]);                          // src/global_faldoi.cpp:648-652
         rgr[r] = recip_f64(gr[r]);
     }
+    const bool ends_warp = (first & 2) != 0;                    // the launch surely ends its warp: ubar is dead afterwards
+    first &= 1;
     if (first) {                                                // start of a warp: ubar = u (:659-660)
 #pragma unroll
         for (int r = 0; r < R; ++r) { ub1[r] = u1[r]; ub2[r] = u2[r]; }
@@ -428,8 +430,10 @@ __device__ __forceinline__ void tvl1_chunk_body(
             const int p = (gy0 + r) * nx + gx;
             dst[0 * plane_elems + p] = u1[r];
             dst[1 * plane_elems + p] = u2[r];
-            dst[2 * plane_elems + p] = ub1[r];
-            dst[3 * plane_elems + p] = ub2[r];
+            if (!ends_warp) {                                   // the next warp starts from ubar = u (:659-660)
+                dst[2 * plane_elems + p] = ub1[r];
+                dst[3 * plane_elems + p] = ub2[r];
+            }
             dst[4 * plane_elems + p] = x11[r];
             dst[5 * plane_elems + p] = x12[r];
             dst[6 * plane_elems + p] = x21[r];
@@ -478,7 +482,9 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
         cur = s_cur; first = s_first; iters = s_iters;
     } else {
         const PairCtl c = ctl[pair];
-        cur = c.cur; first = c.first; iters = c.iters;
+        cur = c.cur; iters = c.iters;
+        // bit 1: this launch ends the warp whatever the tolerance test says (exact-length re-run, or the iteration bound)
+        first = (c.first ? 1 : 0) | ((c.redo || c.n + c.iters >= prm.max_inner) ? 2 : 0);
     }
     if (iters <= 0) return;                     // uniform across the block
 

@@ -41,7 +41,13 @@ __global__ void k(float *out, float seed, double dseed)
             if (OP == 16) a[i] = __shfl_down(a[i], 1);
             if (OP == 17) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0x130, 0xf, 0xf, false));
             if (OP == 18) a[i] = __builtin_fmaxf(a[i], b);
-            if (OP == 19) d[i] = (double)a[i];
+            if (OP == 19) { d[i] = (double)a[i] + d[i]; }                // cvt f32->f64 + add_f64 (2 ops)
+            if (OP == 20) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0x111, 0xf, 0xf, false));   // row_shr:1
+            if (OP == 21) a[i] = a[i] - __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0x130, 0xf, 0xf, true)); // v_sub_f32_dpp wave_shl:1
+            if (OP == 22) a[i] = a[i] - __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0x101, 0xf, 0xf, true)); // v_sub_f32_dpp row_shl:1
+            if (OP == 23) a[i] = (float)__builtin_amdgcn_frexp_expf(a[i]) + b;  // frexp_exp + cvt + add (3 ops)
+            if (OP == 24) a[i] = (float)((double)a[i]);                        // cvt + cvt (2 ops)
+            if (OP == 26) a[i] = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a[i]), 0x8000) ? a[i] : b;       // ds_swizzle
         }
     }
     float s = 0;
@@ -94,6 +100,11 @@ int main()
     run<16>("__shfl_down (bpermute)", 1, out);
     run<17>("dpp wave_shl mov", 1, out);
     run<18>("v_max_f32", 1, out);
-    run<19>("v_cvt_f64_f32", 1, out);
+    run<19>("cvt_f64_f32 + add_f64 (2 ops)", 1, out);
+    run<20>("dpp row_shr:1 mov", 1, out);
+    run<21>("v_sub_f32_dpp wave_shl:1", 1, out);
+    run<22>("v_sub_f32_dpp row_shl:1", 1, out);
+    run<23>("frexp_exp+cvt+add (3 ops)", 1, out);
+    run<24>("cvt f32->f64->f32 (2 ops)", 1, out);
     return 0;
 }
