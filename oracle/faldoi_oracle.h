@@ -101,6 +101,15 @@ float orc_local_tvl1w_estimate(const float *I0, const float *I1, const float *I1
                                int ii, int ij, int ei, int ej, int max_iter_patch, int *iters_out,
                                const float *weight, int iiw, int ijw, int wr_call);
 
+/* ---- the other local functionals, -m 2..7 (faldoi_oracle_local_nl.c; src/energy_model.cpp:691-802, src/nltv_model.cpp,
+ * src/tvcsad_model.cpp, src/nltvcsad_model.cpp and their weighted forms; tables of src/aux_energy_model.cpp) ---- */
+void orc_rgb_to_lab_local(const float *rgb_planar, int size, float *lab_planar);
+void orc_nltv_table_local(const float *lab, int pd, int w, int h, float *wp /*[24][n]*/, float *wt /*[n]*/);
+float orc_local_nl_estimate(int method, const float *I0, const float *I1, const float *I1x, const float *I1y, float *u1,
+                            float *u2, float *duals /*[48][n] or NULL*/, const float *wp /*[24][n] or NULL*/, int nx, int ny,
+                            int ii, int ij, int ei, int ej, int max_iter_patch, const float *weight, int iiw, int ijw,
+                            int wr_call, int *iters_out);
+
 /* src/elap_recsep.c:193-231 and interpolate_poisson, src/local_faldoi.cpp:326-372 */
 void orc_elap_recursive(float *out, const float *in, int w, int h, float timestep, int niter, int scale);
 void orc_interpolate_poisson(float *u1, float *u2, const int *fixed_points, int nx, int ii, int ij, int ei, int ej);

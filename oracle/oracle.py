@@ -18,7 +18,7 @@ def build(force=False):
     """Compile liboracle.so (and _ref when the reference sources are present)."""
     so = os.path.join(_HERE, "liboracle.so")
     import fcntl
-    srcs = [os.path.join(_HERE, f) for f in ("faldoi_oracle.c", "faldoi_oracle_nltv.c", "faldoi_oracle_local.c",
+    srcs = [os.path.join(_HERE, f) for f in ("faldoi_oracle.c", "faldoi_oracle_nltv.c", "faldoi_oracle_local.c", "faldoi_oracle_local_nl.c",
                                              "faldoi_oracle_growing.cpp", "faldoi_oracle.h")]
     fd = os.open(os.path.join(_HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
     try:
@@ -114,6 +114,11 @@ def lib():
         L.orc_queue_free.argtypes = [C.c_void_p]
         L.orc_queue_push.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
         L.orc_queue_pop.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_float)] * 3
+        L.orc_rgb_to_lab_local.argtypes = [_F, C.c_int, _F]
+        L.orc_nltv_table_local.argtypes = [_F, C.c_int, C.c_int, C.c_int, _F, _F]
+        L.orc_local_nl_estimate.restype = C.c_float
+        L.orc_local_nl_estimate.argtypes = [C.c_int, _F, _F, _F, _F, _F, _F, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [
+            _F, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.orc_parts_create.restype = C.c_void_p
         L.orc_parts_create.argtypes = [_F, _F] + [C.c_int] * 5
         L.orc_parts_destroy.argtypes = [C.c_void_p]
