@@ -50,8 +50,10 @@ struct GrowDir {                      // per growing: device pointers (array in 
     int heap_cap;
     int nx, ny;                       // size of the domain this growing runs on (the frame, or one partition of it)
     int shadow;                       // 1: keep the duals and the out-of-window divergence statements in HBM (partitions)
-    int pad;
+    int method;                       // -m: 0 / 1 TV-l2 coupled (plain / weighted), 2..7 the functionals of grow_nl_kernels.hpp
     size_t pe;                        // plane stride of `planes`, `out`, `seed_flow`
+    float *duals;                     // -m 2, 3, 6, 7: the non-local dual values p | q, [48][pe] (persistent across windows)
+    const float *wp;                  // ... and the constant non-local weights, [24][pe]
 };
 
 struct GrowShared {
@@ -65,6 +67,10 @@ struct GrowShared {
     int res[2];                       // harmonic fill: offset of each channel's level-0 result from ver[c][0]
     int cur[4];                       // {have, i, j, pixel}
 };
+
+}  // namespace faldoi
+#include "grow_nl_kernels.hpp"
+namespace faldoi {
 
 // ---------------------------------------------------------------------------------------------
 // interpolate_poisson on the window.  Wavefront c fills flow channel c on its own (no workgroup
@@ -533,7 +539,10 @@ __device__ __forceinline__ void heap_remove_top_wave(Candidate *heap, int &size)
 }
 
 // add_neighbors (src/local_faldoi.cpp:679-727) for the pixel (i, j), all 128 threads.
-__device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir &D, size_t pe, int nx, int ny, int i, int j,
+// FN: which window solver the kernel is built around -- 0: TV-l2 coupled (window_solve); 1: non-local + L1 (-m 2, 3);
+// 2: CSAD alone (-m 4, 5); 3: non-local + CSAD (-m 6); 4: non-local + CSAD over sqrt(|grad|^2) (-m 7).
+template <int FN>
+__device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, const GrowDir &D, size_t pe, int nx, int ny, int i, int j,
                                                   int iteration, int wr, int max_iter_patch, int &heap_size,
                                                   long long &fills, long long *cyc)
 {
@@ -574,7 +583,21 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
     }
     const long long c1 = clock64();
     const int iiw = (i - wr < 0) ? -(i - wr) : 0, ijw = (j - wr < 0) ? -(j - wr) : 0;    // get_relative_index_weight :551-557
-    const float ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2, D.weight, iiw, ijw, wr, D.shadow);
+    float ener;
+    if constexpr (FN == 0)
+        ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2, D.weight, iiw, ijw, wr, D.shadow);
+    else if constexpr (FN == 1)
+        ener = window_solve_nl<true, kDataL1>(sm, *ns, D.planes, D.duals, D.wp, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch,
+                                              u1, u2, D.weight, iiw, ijw, wr, D.method);
+    else if constexpr (FN == 2)
+        ener = window_solve_nl<false, kDataCsad>(sm, *ns, D.planes, D.duals, D.wp, D.planes, pe, nx, ny, ii, ij, ei, ej,
+                                                 max_iter_patch, u1, u2, D.weight, iiw, ijw, wr, D.method);
+    else if constexpr (FN == 3)
+        ener = window_solve_nl<true, kDataCsad>(sm, *ns, D.planes, D.duals, D.wp, D.planes, pe, nx, ny, ii, ij, ei, ej,
+                                                max_iter_patch, u1, u2, D.weight, iiw, ijw, wr, D.method);
+    else
+        ener = window_solve_nl<true, kDataCsadSqrt>(sm, *ns, D.planes, D.duals, D.wp, D.planes, pe, nx, ny, ii, ij, ei, ej,
+                                                    max_iter_patch, u1, u2, D.weight, iiw, ijw, wr, D.method);
     const long long c2 = clock64();
     if (t < 64) {                                                                 // insert_candidates :497-537
         const float ener0 = lane_read(ener, 0);                                   // lane 0 summed the energy
@@ -605,8 +628,9 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, const GrowDir 
 }
 
 // mode 0: the seed pass of insert_initial_seeds (:764-783); mode 1: local_growing (:899-937).
-__device__ __forceinline__ void grow_body(GrowShared &sm, const GrowDir *__restrict__ dirs, int mode, int iteration, int wr,
-                                          int max_iter_patch, int budget)
+template <int FN>
+__device__ __forceinline__ void grow_body(GrowShared &sm, NlShared *ns, const GrowDir *__restrict__ dirs, int mode, int iteration,
+                                          int wr, int max_iter_patch, int budget)
 {
     const GrowDir D = dirs[blockIdx.x];
     const int t = threadIdx.x;
@@ -664,7 +688,7 @@ __device__ __forceinline__ void grow_body(GrowShared &sm, const GrowDir *__restr
         __syncthreads();
         if (!sm.cur[0]) { done = 1; break; }
         const int i = sm.cur[1], j = sm.cur[2];
-        add_neighbors_dev(sm, D, pe, nx, ny, i, j, iteration, mode == 0 ? 1 : wr, max_iter_patch, heap_size, fills, cyc);
+        add_neighbors_dev<FN>(sm, ns, D, pe, nx, ny, i, j, iteration, mode == 0 ? 1 : wr, max_iter_patch, heap_size, fills, cyc);
         if (t == 0) {
             ++solves;
             if (mode == 0) {                                                      // :778-780
@@ -698,14 +722,26 @@ __global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__re
                                                            int max_iter_patch, int budget)
 {
     __shared__ GrowShared sm;
-    grow_body(sm, dirs, mode, iteration, wr, max_iter_patch, budget);
+    grow_body<0>(sm, nullptr, dirs, mode, iteration, wr, max_iter_patch, budget);
 }
 
 __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void grow_kernel_dense(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr, int max_iter_patch, int budget)
 {
     __shared__ GrowShared sm;
-    grow_body(sm, dirs, mode, iteration, wr, max_iter_patch, budget);
+    grow_body<0>(sm, nullptr, dirs, mode, iteration, wr, max_iter_patch, budget);
+}
+
+// The same growing around the window solvers of the other functionals (grow_nl_kernels.hpp): kernels of their own, so
+// that their registers (a 48-entry sorting network, 24 weights) and LDS (the window's dual values) cost the TV-l2 builds
+// nothing.
+template <int FN>
+__global__ __launch_bounds__(kPatchThreads) void grow_kernel_nl(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr,
+                                                              int max_iter_patch, int budget)
+{
+    __shared__ GrowShared sm;
+    __shared__ NlShared ns;
+    grow_body<FN>(sm, &ns, dirs, mode, iteration, wr, max_iter_patch, budget);
 }
 
 // insert_potential_candidates (src/local_faldoi.cpp:813-846) + prepare_data_for_growing (:860-870) for one growing per

@@ -13,7 +13,8 @@
 // image under a name it has no encoder for: ASCII "P2" with one C99 hex-float per line
 // (src/iio.c:3505-3511).  Like the reference, the local step ignores the values of
 // the -p file (src/energy_model.cpp:704-709).
-// Built: -m 0 (TV-l2 coupled) and -m 1 (TV-l2 coupled with weights), with or without image partitions
+// Built: -m 0..7 (TV-l2 coupled, NLTV-L1, TV-CSAD, NLTV-CSAD, each plain / weighted: of_estimation's switch,
+// src/energy_model.cpp:691-802); image partitions with -m 0 / 1
 // (-split_img 1 -h_parts H -v_parts V; not together with saliency maps; -split_img 2, additive: partitions from
 // local iteration 0 on -- faster for one pair, deterministic, but not the reference's flow).  Other functionals are refused loudly.
 #include <cmath>
@@ -78,9 +79,9 @@ int main(int argc, char *argv[])
             fprintf(stderr, "ERROR: the occlusion outputs (TV-l1 with occlusions, -m 8) are not part of this build\n");
             return 2;
         }
-        if (method != 0 && method != 1) {
-            fprintf(stderr, "ERROR: method %d is not available in the local step of this build (TV-l2 coupled -m 0, with "
-                            "weights -m 1)\n", method);
+        if (method < 0 || method > 7) {                       // of_estimation's switch, src/energy_model.cpp:711-800
+            fprintf(stderr, "ERROR: method %d is not available in the local step of this build (functionals 0..7; the occlusion "
+                            "model -m 8 is not built)\n", method);
             return 2;
         }
         if (partial_res != 0) fprintf(stderr, "warning: -partial_res is ignored (no partial results are written)\n");

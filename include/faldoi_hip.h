@@ -251,7 +251,9 @@ typedef struct faldoi_local_params {
     int preprocessed;     /* extension: 1 = i0/i1 are normalised gray planes (skip prepare_stuff's image part) */
     int budget;           /* windows per growing per kernel launch (host relaunches until the queue is empty) */
     int verbose;
-    int method;           /* -m: 0 = TV-l2 coupled (M_TVL1), 1 = TV-l2 coupled with weights (M_TVL1_W, src/tvl2w_model.cpp) */
+    int method;           /* -m: 0 = TV-l2 coupled (M_TVL1), 1 = with weights (M_TVL1_W, src/tvl2w_model.cpp); 2 / 3 = NLTV-L1 (src/nltv_model.cpp) /
+                           * weighted; 4 / 5 = TV-CSAD (src/tvcsad_model.cpp) / weighted; 6 / 7 = NLTV-CSAD (src/nltvcsad_model.cpp) / weighted
+                           * -- of_estimation's switch, src/energy_model.cpp:691-802.  2..7: whole image only, raw RGB frames for 2, 3, 6, 7 */
     int split_img;        /* -split_img: 1 = grow on image partitions from local iteration 1 on (src/aux_partitions.cpp; every pair of a
                            * batch on its own partitions, all of them in one launch).
                            * 2 (additive, not in the reference) = from iteration 0 on: 2*H*V growings in flight all the way */

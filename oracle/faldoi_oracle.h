@@ -123,6 +123,9 @@ void orc_local_faldoi_split(const float *i0n, const float *i1n, const float *go,
                             const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
                             int method, int split_img, int h_parts, int v_parts, int first_h_parts, int first_v_parts,
                             float *out_flow, float *ene_val, long *stats);
+void orc_local_faldoi_raw(const float *i0, const float *i1, int pd, const float *go, const float *ba, const float *sal0,
+                          const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh, int method,
+                          float *out_flow, float *ene_val, long *stats);
 double orc_fb_consistency_check(const float *in0, const float *in1, int *trust, int w, int h, float epsilon);
 void *orc_queue_new(void);
 void orc_queue_free(void *q);

@@ -48,8 +48,10 @@ struct Direction {                 // OpticalFlowData + Tvl2CoupledOFStuff + the
     CandidateQueue queue;
     long pops, solves, fills;
     int max_iter_patch, wr;
-    int method;                    // 0: TV-l2 coupled, 1: with weights (M_TVL1_W)
+    int method;                    // 0: TV-l2 coupled, 1: with weights (M_TVL1_W), 2..7: the other functionals of of_estimation
     std::vector<float> weight;     // gaussian1Dweight(params.w_radio), prepare_stuff src/energy_model.cpp:429-436
+    std::vector<float> duals;      // -m 2, 3, 6, 7: p.sc | q.sc, [48][n], zero where prepare_stuff zeroes them (persistent)
+    const float *wp;               // ... and the constant non-local weights [24][n] (shared by both directions: Lab of i0)
 };
 
 struct Window { int ii, ij, ei, ej; };
@@ -85,7 +87,12 @@ void add_neighbors(Direction &d, int i, int j, int iteration, int wr)
         d.fills++;
     }
     float ener;
-    if (d.method == 1) {                                                 // get_index_weight :571-597 with this call's radius
+    if (d.method >= 2) {                                                 // of_estimation's other branches, src/energy_model.cpp:704-795
+        const int iiw = (i - wr < 0) ? -(i - wr) : 0, ijw = (j - wr < 0) ? -(j - wr) : 0;
+        ener = orc_local_nl_estimate(d.method, d.src, d.dst, d.dstx.data(), d.dsty.data(), u1, u2,
+                                     d.duals.empty() ? NULL : d.duals.data(), d.wp, w, h, x.ii, x.ij, x.ei, x.ej, d.max_iter_patch,
+                                     d.weight.data(), iiw, ijw, wr, NULL);
+    } else if (d.method == 1) {                                          // get_index_weight :571-597 with this call's radius
         const int iiw = (i - wr < 0) ? -(i - wr) : 0, ijw = (j - wr < 0) ? -(j - wr) : 0;
         ener = orc_local_tvl1w_estimate(d.src, d.dst, d.dstx.data(), d.dsty.data(), u1, u2, d.state.data(), w, h, x.ii, x.ij, x.ei,
                                         x.ej, d.max_iter_patch, NULL, d.weight.data(), iiw, ijw, wr);
@@ -225,6 +232,8 @@ void init_direction(Direction &d, const float *src, const float *dst, const floa
     d.ene.assign(n, 0.0f); d.out.assign(2 * n, 0.0f);
     d.fixed.assign(n, 0); d.trust.assign(n, 1);
     d.pops = d.solves = d.fills = 0;
+    d.wp = NULL;
+    d.duals.clear();
 }
 
 }  // namespace
@@ -521,6 +530,50 @@ extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const
             for (Partition &p : *P)
                 for (int k = 0; k < 2; k++) { stats[3 * k] += p.d[k].pops; stats[3 * k + 1] += p.d[k].solves; stats[3 * k + 2] += p.d[k].fills; }
     }
+}
+
+/* match_growing_variational for any functional 0..7 from the RAW frames (planar, pd channels, 0..255): prepare_stuff's
+ * per-method preparation (src/energy_model.cpp:276-686) and then the same growing as above.  -m 2 builds both frames from
+ * i0 (:318-319); the non-local functionals take their weights from the Lab image of i0 for both directions (:322-329 etc.).
+ * Image partitions are only defined for the TV-l2 functionals (upstream README.md:359). */
+extern "C" void orc_local_faldoi_raw(const float *i0, const float *i1, int pd, const float *go, const float *ba, const float *sal0,
+                                     const float *sal1, int w, int h, int wr, int loc_it, int max_iter_patch, float fb_thresh,
+                                     int method, float *out_flow, float *ene_val, long *stats)
+{
+    const size_t n = (size_t)w * h;
+    std::vector<float> a(n), b(n);
+    orc_preprocess_local(i0, method == 2 ? i0 : i1, w, h, pd, a.data(), b.data());
+    if (method < 2) {
+        orc_local_faldoi(a.data(), b.data(), go, ba, sal0, sal1, w, h, wr, loc_it, max_iter_patch, fb_thresh, method, out_flow,
+                         ene_val, stats);
+        return;
+    }
+    const bool nl = method == 2 || method == 3 || method == 6 || method == 7;
+    std::vector<float> lab, wp, wt;
+    if (nl) {
+        lab.resize(n * pd);
+        wp.resize(n * 24);
+        wt.resize(n);
+        orc_rgb_to_lab_local(i0, (int)n, lab.data());
+        orc_nltv_table_local(lab.data(), pd, w, h, wp.data(), wt.data());
+    }
+    Direction d[2];
+    init_direction(d[0], a.data(), b.data(), sal0, w, h, wr, max_iter_patch, method);
+    init_direction(d[1], b.data(), a.data(), sal1, w, h, wr, max_iter_patch, method);
+    for (int k = 0; k < 2; k++)
+        if (nl) { d[k].wp = wp.data(); d[k].duals.assign(n * 48, 0.0f); }
+#pragma omp parallel for num_threads(2)
+    for (int k = 0; k < 2; k++) insert_initial_seeds(d[k], k == 0 ? go : ba);
+    for (int it = 0; it < loc_it; it++) {
+#pragma omp parallel for num_threads(2)
+        for (int k = 0; k < 2; k++) local_growing(d[k], it);
+        prune_and_reseed(d, w, h, fb_thresh);
+    }
+    local_growing(d[0], loc_it);
+    memcpy(out_flow, d[0].out.data(), sizeof(float) * 2 * n);
+    memcpy(ene_val, d[0].ene.data(), sizeof(float) * n);
+    if (stats)
+        for (int k = 0; k < 2; k++) { stats[3 * k] = d[k].pops; stats[3 * k + 1] = d[k].solves; stats[3 * k + 2] = d[k].fills; }
 }
 
 extern "C" void orc_local_faldoi(const float *i0n, const float *i1n, const float *go, const float *ba, const float *sal0,

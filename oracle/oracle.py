@@ -108,6 +108,8 @@ def lib():
                                        np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
         L.orc_local_faldoi_split.argtypes = [_F, _F, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float] + [C.c_int] * 6 + [
             _F, _F, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
+        L.orc_local_faldoi_raw.argtypes = [_F, _F, C.c_int, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float, C.c_int, _F, _F,
+                                           np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
         L.orc_fb_consistency_check.argtypes = [_F, _F, _I, C.c_int, C.c_int, C.c_float]
         L.orc_fb_consistency_check.restype = C.c_double
         L.orc_queue_new.restype = C.c_void_p
@@ -470,6 +472,15 @@ def local_faldoi(i0n, i1n, go, ba, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2
     ptr = [k.ctypes.data if k is not None else None for k in keep]
     lib().orc_local_faldoi_split(i0n, i1n, go, ba, ptr[0], ptr[1], w, h, wr, loc_it, max_iter_patch, fb_thresh, method,
                                  split_img, h_parts, v_parts, first_h_parts, first_v_parts, out, ene, st)
+    return out, ene, st
+
+
+def local_faldoi_raw(i0, i1, go, ba, method, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2.0):
+    """match_growing_variational for any functional 0..7 from the raw (pd,h,w) frames (whole image)."""
+    i0, i1, go, ba = f32(i0), f32(i1), f32(go), f32(ba)
+    pd, h, w = i0.shape
+    out, ene, st = np.empty((2, h, w), np.float32), np.empty((h, w), np.float32), np.zeros(6, np.int64)
+    lib().orc_local_faldoi_raw(i0, i1, pd, go, ba, None, None, w, h, wr, loc_it, max_iter_patch, fb_thresh, method, out, ene, st)
     return out, ene, st
 
 

@@ -1000,3 +1000,33 @@ def test_nltvcsad_full_size_bounded_schedule_and_determinism(ctx, oracle):
     oc = oracle.nltvcsad_global(i0n, i1n, lab, u0, warps=2, max_inner=20)
     assert bits_equal(uc, oc), mismatch_report(uc, oc)
     print("configs[4] 1024x436: 1 x 400 iterations %.1f / %.1f ms on the device" % (ms_a, ms_b))
+
+
+# ------------------------------------------------------------------ the other local functionals
+@pytest.mark.parametrize("method", [2, 3, 4, 5, 6, 7])
+def test_match_growing_other_functionals_bit_exact(ctx, oracle, method):
+    """The whole local step with of_estimation's other branches (-m 2..7: NLTV-L1, TV-CSAD, NLTV-CSAD, plain and
+    weighted), every candidate on the device in the reference's order, against the CPU checker -- whose window
+    operators and tables are pinned bit for bit to the reference's compiled objects (tests/test_oracle_models_cpu.py):
+    flow, energy map and the pop / window / fill counts."""
+    crop = (400, 150, 56, 40) if method < 4 else (400, 150, 40, 30)       # the CPU checker sorts 97 floats per pixel-iteration
+    i0, i1 = sintel_pair(crop)
+    a, b = oracle.preprocess_local(i0, i1)
+    go, ba = _seed_flows(oracle, a, b, 0.02, seed=method)
+    want, want_ene, st = oracle.local_faldoi_raw(i0, i1, go, ba, method)
+    got, got_ene, gst = ctx.match_growing(i0, i1, go, ba, method=method, budget=2000)
+    assert list(gst.pops) == [st[0], st[3]] and list(gst.solves) == [st[1], st[4]] and list(gst.fills) == [st[2], st[5]]
+    assert float(F.flo.epe(got, want).mean()) <= EPE_GATE
+    assert bits_equal(got, want), mismatch_report(got, want)
+    assert bits_equal(got_ene, want_ene), mismatch_report(got_ene, want_ene)
+
+
+def test_match_growing_other_functionals_argument_checks(ctx):
+    i0, i1 = sintel_pair((400, 150, 40, 30))
+    z = np.full((2, 30, 40), np.nan, np.float32)
+    with pytest.raises(F.capi.FaldoiError):          # partitions are a TV-l2 feature
+        ctx.match_growing(i0, i1, z, z, method=2, split_img=1)
+    with pytest.raises(F.capi.FaldoiError):          # Lab weights need the raw RGB frames
+        ctx.match_growing(i0[0], i1[0], z, z, method=6)
+    with pytest.raises(F.capi.FaldoiError):
+        ctx.match_growing(i0, i1, z, z, method=8)
