@@ -116,7 +116,7 @@ def test_local_faldoi_cli_argument_handling(bins, tmp_path):
     s0 = tmp_path / "s0.flo"
     F.flo.write_flo(str(s0), seeds)
     base = [exe, str(ims), str(s0), str(s0), str(tmp_path / "o.flo"), str(tmp_path / "sim.tiff")]
-    r = subprocess.run(base + ["-m", "2"], capture_output=True, text=True)          # functional not built
+    r = subprocess.run(base + ["-m", "8"], capture_output=True, text=True)          # the occlusion model is not built
     assert r.returncode == 2 and "not available" in r.stderr
     r = subprocess.run(base + ["occ.png"], capture_output=True, text=True)          # occlusion outputs not built
     assert r.returncode == 2
