@@ -221,6 +221,34 @@ __device__ __forceinline__ float bicubic_eval(const float *__restrict__ img, con
     return keys_cubic(col[0], col[1], col[2], col[3], t.tx);
 }
 
+// The same evaluation for a pixel NONE of whose tap indices was clamped: the four tap columns are then the consecutive
+// columns x0 .. x0+3 (ascending for sx = +1, descending for sx = -1), so every tap row is ONE 16-byte load instead of
+// four 4-byte gathers -- the per-warp kernel is bound by the number of vector-memory instructions (64 lane addresses
+// each), not by bytes.  The loads are only 4-byte aligned; gfx950 takes unaligned dwordx4 global loads.
+struct __attribute__((packed, aligned(4))) TapRow { float c0, c1, c2, c3; };
+__device__ __forceinline__ float bicubic_eval_rows(const float *__restrict__ img, const BicubicTaps &t, int nx)
+{
+    const bool asc = t.X[0] < t.X[1];
+    const int x0 = asc ? t.X[0] : t.X[3];
+    const TapRow r0 = *reinterpret_cast<const TapRow *>(img + x0 + nx * t.Y[0]);
+    const TapRow r1 = *reinterpret_cast<const TapRow *>(img + x0 + nx * t.Y[1]);
+    const TapRow r2 = *reinterpret_cast<const TapRow *>(img + x0 + nx * t.Y[2]);
+    const TapRow r3 = *reinterpret_cast<const TapRow *>(img + x0 + nx * t.Y[3]);
+    const float k0 = keys_cubic(r0.c0, r1.c0, r2.c0, r3.c0, t.ty);          // column x0 ... x0+3, rows in the reference's order
+    const float k1 = keys_cubic(r0.c1, r1.c1, r2.c1, r3.c1, t.ty);
+    const float k2 = keys_cubic(r0.c2, r1.c2, r2.c2, r3.c2, t.ty);
+    const float k3 = keys_cubic(r0.c3, r1.c3, r2.c3, r3.c3, t.ty);
+    return keys_cubic(asc ? k0 : k3, asc ? k1 : k2, asc ? k2 : k1, asc ? k3 : k0, t.tx);
+}
+
+// border_out = false call sites (clamped taps are legal there): the row form when no lane of the wavefront has a clamped
+// tap, the gather form for the whole wavefront otherwise (near the image frame).  any_clamped is wave-uniform.
+__device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0ull; }
+__device__ __forceinline__ float bicubic_eval_any(const float *__restrict__ img, const BicubicTaps &t, int nx, bool any_clamped)
+{
+    return any_clamped ? bicubic_eval(img, t, nx) : bicubic_eval_rows(img, t, nx);
+}
+
 // ---------------------------------------------------------------------------------------------
 // TV-L1 per-pixel steps, src/global_faldoi.cpp.
 // ---------------------------------------------------------------------------------------------

@@ -263,21 +263,21 @@ static void pick_schedule(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *
 template <int R, int NW>
 static hipError_t launch_chunk_t(dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int ntx, int nty,
                                  int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st, int cur,
-                                 int first, int iters, int slot)
+                                 int first, int iters, int slot, unsigned long long *stamps)
 {
     hipLaunchKernelGGL((tvl1_chunk_kernel<R, NW>), grid, dim3(64 * NW), 0, s, base, pe, nx, ny, ntx, nty, npairs, halo,
-                       prm, ctl, err, st, cur, first, iters, slot);
+                       prm, ctl, err, st, cur, first, iters, slot, stamps);
     return hipGetLastError();
 }
 
 static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int ntx,
                                int nty, int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st,
-                               int cur, int first, int iters, int slot)
+                               int cur, int first, int iters, int slot, unsigned long long *stamps = nullptr)
 {
 #define FALDOI_CASE(r, w)                                                                                             \
     if (tc.R == r && tc.NW == w)                                                                                      \
         return launch_chunk_t<r, w>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, first, \
-                                    iters, slot);
+                                    iters, slot, stamps);
     FALDOI_CASE(4, 16)
     FALDOI_CASE(3, 12)
     FALDOI_CASE(4, 12)
@@ -293,12 +293,15 @@ static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base
 static void launch_warp(int variant, dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int npairs,
                         const PairCtl *ctl, int st, int cur)
 {
+    // FALDOI_WARP_LDS=bytes (tuning aid): unused dynamic LDS per workgroup, which caps how many workgroups a CU keeps resident
+    // (the kernel's waves all gather, then all compute; fewer resident waves stagger the two phases)
+    static const int lds = [] { const char *v = getenv("FALDOI_WARP_LDS"); const int b = v ? atoi(v) : 0; return b > 0 && b <= 65536 ? b : 0; }();
     if (variant == 8)
-        hipLaunchKernelGGL(tvl1_warp_kernel<8>, grid, dim3(256), 0, s, base, pe, nx, ny, npairs, ctl, st, cur);
+        hipLaunchKernelGGL(tvl1_warp_kernel<8>, grid, dim3(256), lds, s, base, pe, nx, ny, npairs, ctl, st, cur);
     else if (variant == 6)
-        hipLaunchKernelGGL(tvl1_warp_kernel<6>, grid, dim3(256), 0, s, base, pe, nx, ny, npairs, ctl, st, cur);
+        hipLaunchKernelGGL(tvl1_warp_kernel<6>, grid, dim3(256), lds, s, base, pe, nx, ny, npairs, ctl, st, cur);
     else
-        hipLaunchKernelGGL(tvl1_warp_kernel<4>, grid, dim3(256), 0, s, base, pe, nx, ny, npairs, ctl, st, cur);
+        hipLaunchKernelGGL(tvl1_warp_kernel<4>, grid, dim3(256), lds, s, base, pe, nx, ny, npairs, ctl, st, cur);
 }
 
 // ------------------------------------------------------------------------------------------ batch
@@ -501,6 +504,15 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
             b->ev.push_back(e);
         }
     }
+    // FALDOI_STAMPS=1 (measurement aid): one launch in the middle of the solve records, per workgroup, when it started, when
+    // its loads had landed, when its iterations ended and when its stores had drained (constant 100 MHz clock)
+    unsigned long long *d_stamps = nullptr;
+    DevBuf stamp_buf;
+    if (!dynamic && getenv("FALDOI_STAMPS") && atoi(getenv("FALDOI_STAMPS")) > 0) {
+        HIP_TRY(hipMalloc((void **)&stamp_buf.p, sizeof(unsigned long long) * 4 * grid.x));
+        d_stamps = reinterpret_cast<unsigned long long *>(stamp_buf.p);
+        HIP_TRY(hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * 4 * grid.x, s));
+    }
     if (!dynamic) {
         int cur = 0;
         int last_iters = chunk;
@@ -518,7 +530,8 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
                 }
                 if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
                 HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
-                                     b->ctl, b->err_part, 1, cur, (n == 0 ? 1 : 0) | (n + it >= prm->max_inner ? 2 : 0), it, w));
+                                     b->ctl, b->err_part, 1, cur, (n == 0 ? 1 : 0) | (n + it >= prm->max_inner ? 2 : 0), it, w,
+                                     (d_stamps && w == warps / 2 && n == 0) ? d_stamps : nullptr));
                 if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
                 ++launches;
                 cur ^= 1;
@@ -566,6 +579,27 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         chunk_ms += t;
     }
 
+    if (d_stamps) {
+        std::vector<unsigned long long> hs((size_t)4 * total_tiles);
+        HIP_TRY(hipMemcpy(hs.data(), d_stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, tend = 0;
+        for (int q = 0; q < total_tiles; ++q) { if (hs[4 * q] && hs[4 * q] < t0) t0 = hs[4 * q]; if (hs[4 * q + 3] > tend) tend = hs[4 * q + 3]; }
+        double sum[4] = { 0, 0, 0, 0 }, mx[4] = { 0, 0, 0, 0 };
+        for (int q = 0; q < total_tiles; ++q)
+            for (int c = 0; c < 4; ++c) {
+                const double us = (double)(hs[4 * q + c] - t0) * 0.01;
+                sum[c] += us;
+                if (us > mx[c]) mx[c] = us;
+            }
+        if (atoi(getenv("FALDOI_STAMPS")) > 1)                       // the iteration phase of every tile, as a grid
+            for (int ty = 0; ty < nty; ++ty) {
+                for (int tx = 0; tx < ntx; ++tx) fprintf(stderr, "%5.1f", (double)(hs[4 * (ty * ntx + tx) + 2] - hs[4 * (ty * ntx + tx) + 1]) * 0.01);
+                fprintf(stderr, "\n");
+            }
+        fprintf(stderr, "faldoi stamps (us after the first workgroup started; mean / max over %d workgroups): start %.2f / %.2f, loads landed "
+                        "%.2f / %.2f, iterations done %.2f / %.2f, stores drained %.2f / %.2f\n", total_tiles, sum[0] / total_tiles, mx[0],
+                sum[1] / total_tiles, mx[1], sum[2] / total_tiles, mx[2], sum[3] / total_tiles, mx[3]);
+    }
     std::vector<int> h_it((size_t)warps * b->npairs);
     std::vector<float> h_er((size_t)warps * b->npairs);
     HIP_TRY(hipMemcpy(h_it.data(), b->d_iters, sizeof(int) * h_it.size(), hipMemcpyDeviceToHost));

@@ -325,9 +325,10 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         i0 = I0[p];
         const float uu = (float)k + u1, vv = (float)l + u2;                       // src/bicubic_interpolation.c:288-289
         const BicubicTaps tp = bicubic_taps(uu, vv, nx, ny);                      // border_out = false
-        const float w0 = bicubic_eval(I1, tp, nx);
-        wx = bicubic_eval(I1x, tp, nx);
-        wy = bicubic_eval(I1y, tp, nx);
+        const bool anyc = wave_any(tp.clamped);
+        const float w0 = bicubic_eval_any(I1, tp, nx, anyc);
+        wx = bicubic_eval_any(I1x, tp, nx, anyc);
+        wy = bicubic_eval_any(I1y, tp, nx, anyc);
         gr = grad_sq(wx, wy);
         rc = rho_const(w0, wx, wy, u1, u2, i0);
         rgrad = recip_f64(gr);
@@ -419,7 +420,7 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         const float u1x = !last_col ? ar - u1 : 0.0f, u1y = !last_row ? ad - u1 : 0.0f;
         const float u2x = !last_col ? br - u2 : 0.0f, u2y = !last_row ? bd - u2 : 0.0f;
         const BicubicTaps tp = bicubic_taps((float)k + u1, (float)l + u2, nx, ny);
-        const float iw = bicubic_eval(I1, tp, nx);
+        const float iw = bicubic_eval_any(I1, tp, nx, wave_any(tp.clamped));
         const float dt = weight ? (float)((double)lambda * __builtin_fabs((double)(iw - i0)) * (double)gwy * (double)gwx)
                                 : lambda * __builtin_fabsf(iw - i0);
         const float dc = (1 / (2 * theta)) * ((u1 - v1) * (u1 - v1) + (u2 - v2) * (u2 - v2));
@@ -841,8 +842,8 @@ __global__ void grow_prune_kernel(const float *__restrict__ in0, const float *__
         const int y = p / nx, x = p - y * nx;
         const float a = in0[p], b = in0[pe + p];
         const BicubicTaps tp = bicubic_taps((float)x + a, (float)y + b, nx, ny);
-        const float u1w = tp.clamped ? 0.0f : bicubic_eval(in1, tp, nx);          // border_out = true
-        const float u2w = tp.clamped ? 0.0f : bicubic_eval(in1 + pe, tp, nx);
+        const float u1w = tp.clamped ? 0.0f : bicubic_eval_rows(in1, tp, nx);          // border_out = true
+        const float u2w = tp.clamped ? 0.0f : bicubic_eval_rows(in1 + pe, tp, nx);
         const float sx = a + u1w, sy = b + u2w;
         float tolerance;
         if (__builtin_isinf(sx) || __builtin_isinf(sy)) tolerance = __builtin_inff();

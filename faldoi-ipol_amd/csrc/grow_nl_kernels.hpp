@@ -98,9 +98,10 @@ __device__ __forceinline__ float window_solve_nl(GrowShared &sm, NlShared &ns, c
     if (act) {
         i0 = I0[p];
         const BicubicTaps tp = bicubic_taps((float)k + u1, (float)l + u2, nx, ny);      // border_out = false
-        i1w = bicubic_eval(I1, tp, nx);
-        wx = bicubic_eval(I1x, tp, nx);
-        wy = bicubic_eval(I1y, tp, nx);
+        const bool anyc = wave_any(tp.clamped);
+        i1w = bicubic_eval_any(I1, tp, nx, anyc);
+        wx = bicubic_eval_any(I1x, tp, nx, anyc);
+        wy = bicubic_eval_any(I1y, tp, nx, anyc);
         const float g2 = grad_sq(wx, wy);
         if (DATA == kDataL1) {
             gr = g2;
@@ -262,7 +263,7 @@ __device__ __forceinline__ float window_solve_nl(GrowShared &sm, NlShared &ns, c
     float i1n = 0.0f;
     if (act) {
         const BicubicTaps tp = bicubic_taps((float)k + u1, (float)l + u2, nx, ny);
-        i1n = bicubic_eval(I1, tp, nx);
+        i1n = bicubic_eval_any(I1, tp, nx, wave_any(tp.clamped));
     }
     sm.a[t] = u1;
     sm.b[t] = u2;

@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void nl_warp_kernel(float *__restrict__ base, 
     const BicubicTaps tp = bicubic_taps((float)x + u1, (float)y + u2, nx, ny);
     float w0 = 0.0f, wx = 0.0f, wy = 0.0f;
     if (!tp.clamped) {
-        w0 = bicubic_eval(base + N_I1 * pe, tp, nx);
-        wx = bicubic_eval(base + N_I1X * pe, tp, nx);
-        wy = bicubic_eval(base + N_I1Y * pe, tp, nx);
+        w0 = bicubic_eval_rows(base + N_I1 * pe, tp, nx);
+        wx = bicubic_eval_rows(base + N_I1X * pe, tp, nx);
+        wy = bicubic_eval_rows(base + N_I1Y * pe, tp, nx);
     }
     base[N_I1W * pe + p] = data_l1 ? rho_const(w0, wx, wy, u1, u2, base[N_I0 * pe + p]) : w0;
     base[N_I1WX * pe + p] = wx;
@@ -296,9 +296,9 @@ __global__ __launch_bounds__(256) void tc_warp_kernel(float *__restrict__ base, 
     const BicubicTaps tp = bicubic_taps((float)x + u1, (float)y + u2, nx, ny);
     float w0 = 0.0f, wx = 0.0f, wy = 0.0f;
     if (!tp.clamped) {
-        w0 = bicubic_eval(base + C_I1 * pe, tp, nx);
-        wx = bicubic_eval(base + C_I1X * pe, tp, nx);
-        wy = bicubic_eval(base + C_I1Y * pe, tp, nx);
+        w0 = bicubic_eval_rows(base + C_I1 * pe, tp, nx);
+        wx = bicubic_eval_rows(base + C_I1X * pe, tp, nx);
+        wy = bicubic_eval_rows(base + C_I1Y * pe, tp, nx);
     }
     base[C_I1W * pe + p] = w0;
     base[C_I1WX * pe + p] = wx;

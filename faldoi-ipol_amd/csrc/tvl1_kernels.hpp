@@ -115,7 +115,7 @@ __global__ void bicubic_warp_kernel(const float *__restrict__ in, const float *_
         const float uu = (float)x + u[p];
         const float vv = (float)y + v[p];
         const BicubicTaps t = bicubic_taps(uu, vv, nx, ny);
-        out[p] = (t.clamped && border_out) ? 0.0f : bicubic_eval(in, t, nx);
+        out[p] = (t.clamped && border_out) ? 0.0f : (t.clamped ? bicubic_eval(in, t, nx) : bicubic_eval_rows(in, t, nx));
     }
 }
 
@@ -260,9 +260,9 @@ __global__ __launch_bounds__(256, WPS) void tvl1_warp_kernel(float *__restrict__
     const BicubicTaps tp = bicubic_taps(uu, vv, nx, ny);
     float w0 = 0.0f, wx = 0.0f, wy = 0.0f;                      // border_out = true (:635-637)
     if (!tp.clamped) {
-        w0 = bicubic_eval(I1, tp, nx);
-        wx = bicubic_eval(I1x, tp, nx);
-        wy = bicubic_eval(I1y, tp, nx);
+        w0 = bicubic_eval_rows(I1, tp, nx);
+        wx = bicubic_eval_rows(I1x, tp, nx);
+        wy = bicubic_eval_rows(I1y, tp, nx);
     }
     slab[(size_t)P_RC * plane_elems + p] = rho_const(w0, wx, wy, u1, u2, i0v);
     slab[(size_t)P_IWX * plane_elems + p] = wx;
@@ -288,13 +288,13 @@ __global__ __launch_bounds__(256, WPS) void tvl1_warp_kernel(float *__restrict__
 // BORDER = false is the specialisation for tiles whose 64 x TH footprint contains no pixel of
 // the image frame (first/last row or column): every stencil uses the interior formula, no
 // per-pixel class selects.  Chosen per workgroup (uniform branch) by the kernel below.
-template <int R, int NW, bool BORDER>
+template <int R, int NW, int BORDER>
 __device__ __forceinline__ void tvl1_chunk_body(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int npairs, int ntiles, int t,
     int pair, int txi, int tyi, int halo, const TvConst &prm, float *__restrict__ err_out,
     int cur, int first /* bit 0: starts a warp, bit 1: ends one */, int iters, int err_slot,
     float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW], float (*s_x22)[kTileW],
-    unsigned (*s_err)[kTileW])
+    unsigned (*s_err)[kTileW], unsigned long long *stamps)
 {
     constexpr int TH = R * NW;
     const int lane = threadIdx.x & 63;
@@ -350,12 +350,21 @@ __device__ __forceinline__ void tvl1_chunk_body(
         }
     }
 
+    // measurement aid (FALDOI_STAMPS=1, never in a timed run): when do the loads land, the iterations end, the stores drain
+    if (stamps && threadIdx.x == 0) {
+        float sink = u1[R - 1] + x22[R - 1] + rc[R - 1] + iy[R - 1];
+        asm volatile("" : "+v"(sink));                                // all loads of this wave have landed
+        stamps[4 * t + 1] = __builtin_amdgcn_s_memrealtime();
+    }
     for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;
     s_ub1[wv][lane] = ub1[0];
     s_ub2[wv][lane] = ub2[0];
 
-    const bool last_c = BORDER && (gx == nx - 1);
-    const bool first_c = BORDER && (gx == 0);
+    // BORDER bit 0: the tile footprint contains image column 0 or nx-1; bit 1: row 0 or ny-1.  A tile on the left or right
+    // edge only (most border tiles) keeps the row formulas of the interior, and vice versa.
+    constexpr bool COLB = (BORDER & 1) != 0, ROWB = (BORDER & 2) != 0;
+    const bool last_c = COLB && (gx == nx - 1);
+    const bool first_c = COLB && (gx == 0);
 
     for (int it = 0; it < iters; ++it) {
         // Rows whose values can still reach the owned rows [halo, TH-halo) before the launch ends:
@@ -378,7 +387,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
                 const float r2 = lane_right(ub2[r]);
                 const float d1 = (r < R - 1) ? ub1[r < R - 1 ? r + 1 : r] : dn1;
                 const float d2 = (r < R - 1) ? ub2[r < R - 1 ? r + 1 : r] : dn2;
-                const bool last_r = BORDER && (gy0 + r == ny - 1);
+                const bool last_r = ROWB && (gy0 + r == ny - 1);
                 dual_step(x11[r], x12[r], x21[r], x22[r],
                           fwd_diff(r1, ub1[r], last_c), fwd_diff(d1, ub1[r], last_r),
                           fwd_diff(r2, ub2[r], last_c), fwd_diff(d2, ub2[r], last_r), prm.tau);
@@ -402,7 +411,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
                 const float t22 = (r > 0) ? x22[r > 0 ? r - 1 : 0] : up22;
                 float div1, div2;
                 if (BORDER) {
-                    const PixClass pc{ first_c, last_c, gy == 0, gy == ny - 1 };
+                    const PixClass pc{ first_c, last_c, ROWB && gy == 0, ROWB && gy == ny - 1 };
                     div1 = div_sample(x11[r], l11, x12[r], t12, pc);
                     div2 = div_sample(x21[r], l21, x22[r], t22, pc);
                 } else {                                       // src/utils.cpp:250-256
@@ -423,6 +432,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
         }
     }
 
+    if (stamps && threadIdx.x == 0) stamps[4 * t + 2] = __builtin_amdgcn_s_memrealtime();
     // ---- store the owned interior into the other state buffer ----
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -441,6 +451,10 @@ __device__ __forceinline__ void tvl1_chunk_body(
         }
     }
     __syncthreads();
+    if (stamps && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamps[4 * t + 3] = __builtin_amdgcn_s_memrealtime();
+    }
     // wave i reduces iteration i's 64 per-lane maxima
     for (int i = wv; i < kMaxChunk; i += NW) {
         float m = (i < iters) ? __uint_as_float(s_err[i][lane]) : 0.0f;
@@ -460,7 +474,7 @@ template <int R, int NW>
 __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int ntx, int nty, int npairs,
     int halo, TvConst prm, const PairCtl *__restrict__ ctl, float *__restrict__ err_out,
-    int static_mode, int s_cur, int s_first, int s_iters, int err_slot)
+    int static_mode, int s_cur, int s_first, int s_iters, int err_slot, unsigned long long *stamps)
 {
     constexpr int TH = R * NW;
     __shared__ float s_ub1[NW][kTileW];
@@ -473,6 +487,7 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     const int ntiles = ntx * nty;
     if (t >= ntiles * npairs) return;
+    if (stamps && threadIdx.x == 0) stamps[4 * t] = __builtin_amdgcn_s_memrealtime();
     const int pair = t / ntiles;
     const int tile = t - pair * ntiles;
     const int tyi = tile / ntx, txi = tile - tyi * ntx;
@@ -490,13 +505,15 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
 
     // does the tile footprint [X0, X0+64) x [Y0, Y0+TH) touch the image frame?
     const int X0 = txi * (kTileW - 2 * halo) - halo, Y0 = tyi * (TH - 2 * halo) - halo;
-    const bool border = X0 <= 0 || X0 + kTileW >= nx || Y0 <= 0 || Y0 + TH >= ny;
-    if (border)
-        tvl1_chunk_body<R, NW, true>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out,
-                                     cur, first, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err);
-    else
-        tvl1_chunk_body<R, NW, false>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out,
-                                      cur, first, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err);
+    const bool colb = X0 <= 0 || X0 + kTileW >= nx, rowb = Y0 <= 0 || Y0 + TH >= ny;
+#define FALDOI_BODY(B)                                                                                                  \
+    tvl1_chunk_body<R, NW, B>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out, cur,   \
+                              first, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err, stamps)
+    if (colb && rowb) FALDOI_BODY(3);
+    else if (colb) FALDOI_BODY(1);
+    else if (rowb) FALDOI_BODY(2);
+    else FALDOI_BODY(0);
+#undef FALDOI_BODY
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -157,6 +157,13 @@ void insert_initial_seeds(Direction &d, const float *in_flow)
         }
 }
 
+// Study hook (tools/growing_dependencies.py): the order in which the forward growing minimises its windows.
+static int *g_trace = NULL;
+static long g_trace_cap = 0, g_trace_len = 0;
+static const Direction *g_trace_dir = NULL;
+extern "C" void orc_trace_windows(int *buf, long cap) { g_trace = buf; g_trace_cap = cap; g_trace_len = 0; g_trace_dir = NULL; }
+extern "C" long orc_trace_length(void) { return g_trace_len; }
+
 // local_growing, src/local_faldoi.cpp:891-1039 (without the partial-result dumps)
 void local_growing(Direction &d, int iteration)
 {
@@ -171,6 +178,11 @@ void local_growing(Direction &d, int iteration)
         d.out[p] = c.u;
         d.out[n + p] = c.v;
         d.ene[p] = c.sim;
+        if (g_trace && (g_trace_dir == NULL || g_trace_dir == &d)) {
+            g_trace_dir = &d;                                             // the first growing that gets here (one direction)
+            if (g_trace_len + 3 <= g_trace_cap) { g_trace[g_trace_len] = c.i; g_trace[g_trace_len + 1] = c.j; g_trace[g_trace_len + 2] = iteration; }
+            g_trace_len += 3;
+        }
         add_neighbors(d, c.i, c.j, iteration, d.wr);
     }
 }
