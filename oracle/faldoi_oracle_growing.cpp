@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <queue>
+#include <set>
 #include <vector>
 
 extern "C" {
@@ -29,6 +30,7 @@ namespace {
 struct Candidate {                 // SparseOF, src/energy_structures.h:13-20
     int i, j;                      // column, row
     float u, v, sim;
+    long id;                       // study only (speculation model below): order of insertion; never compared
 };
 struct CandidateOrder {            // CompareSparseOF :22-27: smallest energy on top
     bool operator()(const Candidate &a, const Candidate &b) const { return a.sim > b.sim; }
@@ -64,6 +66,108 @@ Window window_at(int wr, int w, int h, int i, int j)      // get_index_patch, sr
     x.ei = (i + 1 + wr > w) ? w : i + 1 + wr;
     x.ej = (j + 1 + wr > h) ? h : j + 1 + wr;
     return x;
+}
+
+// ---- study (tools/growing_dependencies.py --spec S): a cost model of a committer + S speculative window solvers working on
+// one growing.  It observes the real run (which stays untouched) and adds up modelled cycles: the committer pops in the
+// true order; a free solver takes the best queued candidate nobody works on; a popped candidate whose solver has finished
+// and whose window no commit has touched since that solver started costs only the queue work and the write-back.
+struct SpecModel {
+    int S = 0;
+    const Direction *dir = NULL;
+    double T = 0, T_serial = 0;
+    long hits = 0, misses = 0, waits = 0, windows = 0, serial = 0;
+    struct Solver { long cand = -1; double done = 0; long start_serial = 0; };
+    std::vector<Solver> solver;
+    std::vector<int> log_i, log_j;                       // commit log by serial number
+    std::set<std::pair<float, long> > order;             // (energy, id) of the queued candidates: a stand-in for "the top of the queue"
+    std::vector<Candidate> byid;
+    double c_pop = 4500, c_push = 2200, c_fill = 31700, c_solve = 15500, c_apply = 2500;
+};
+static SpecModel g_spec;
+extern "C" void orc_spec_model(int solvers) { g_spec = SpecModel(); g_spec.S = solvers; g_spec.solver.resize(solvers > 0 ? solvers : 0); }
+extern "C" void orc_spec_report(double *out)
+{
+    out[0] = g_spec.T; out[1] = g_spec.T_serial; out[2] = (double)g_spec.hits; out[3] = (double)g_spec.misses;
+    out[4] = (double)g_spec.waits; out[5] = (double)g_spec.windows;
+}
+static void spec_on_push(Direction &d, Candidate &c)
+{
+    if (g_spec.S <= 0 || (g_spec.dir && g_spec.dir != &d)) return;
+    g_spec.dir = &d;
+    c.id = (long)g_spec.byid.size();
+    g_spec.byid.push_back(c);
+    g_spec.order.insert(std::make_pair(c.sim, c.id));
+    g_spec.T += g_spec.c_push;
+    g_spec.T_serial += g_spec.c_push;
+}
+static bool spec_needs_fill(const Direction &d, int i, int j, int iteration)
+{
+    if (iteration == 0) return true;
+    const Window x = window_at(d.wr, d.w, d.h, i, j);
+    for (int l = x.ij; l < x.ej; l++)
+        for (int k = x.ii; k < x.ei; k++)
+            if (d.trust[l * d.w + k] == 0) return true;
+    return false;
+}
+// called at every pop of the observed growing, before the window is processed
+static void spec_on_pop(Direction &d, const Candidate &c, bool stale, int iteration)
+{
+    SpecModel &m = g_spec;
+    if (m.S <= 0 || m.dir != &d) return;
+    m.order.erase(std::make_pair(c.sim, c.id));
+    m.T += m.c_pop;
+    m.T_serial += m.c_pop;
+    if (stale) return;
+    const double full = (spec_needs_fill(d, c.i, c.j, iteration) ? m.c_fill : 0.0) + m.c_solve;
+    m.T_serial += full;
+    m.windows++;
+    bool served = false;
+    for (SpecModel::Solver &sv : m.solver)
+        if (sv.cand == c.id) {
+            bool valid = true;
+            for (long q = sv.start_serial; q < m.serial && valid; q++)
+                if (std::abs(m.log_i[q] - c.i) <= 2 * d.wr && std::abs(m.log_j[q] - c.j) <= 2 * d.wr) valid = false;
+            if (valid && sv.done <= m.T) { m.T += m.c_apply; m.hits++; served = true; }
+            else if (valid && sv.done + m.c_apply < m.T + full) { m.T = sv.done + m.c_apply; m.waits++; served = true; }
+            sv.cand = -1;
+        }
+    if (!served) { m.T += full; m.misses++; }
+    m.log_i.push_back(c.i);
+    m.log_j.push_back(c.j);
+    m.serial++;
+}
+// after the window's pushes: idle solvers pick work
+static void spec_assign(Direction &d, int iteration)
+{
+    SpecModel &m = g_spec;
+    if (m.S <= 0 || m.dir != &d) return;
+    for (SpecModel::Solver &sv : m.solver) {
+        if (sv.cand >= 0 && sv.done > m.T) continue;                      // busy
+        if (sv.cand >= 0) continue;                                       // holds a finished result until its candidate is popped
+        int looked = 0;
+        for (std::set<std::pair<float, long> >::iterator it = m.order.begin(); it != m.order.end() && looked < 4 * m.S + 4; ++it, ++looked) {
+            const Candidate &q = m.byid[it->second];
+            if (d.fixed[q.j * d.w + q.i]) continue;
+            bool taken = false;
+            for (const SpecModel::Solver &o : m.solver) taken = taken || o.cand == q.id;
+            if (taken) continue;
+            if (looked == 0) continue;                                    // the very next pop is the committer's own
+            sv.cand = q.id;
+            sv.start_serial = m.serial;
+            sv.done = m.T + (spec_needs_fill(d, q.i, q.j, iteration) ? m.c_fill : 0.0) + m.c_solve;
+            break;
+        }
+    }
+    // a held result whose candidate became stale (its pixel got fixed) or invalid is dropped
+    for (SpecModel::Solver &sv : m.solver)
+        if (sv.cand >= 0) {
+            const Candidate &q = m.byid[sv.cand];
+            bool drop = d.fixed[q.j * d.w + q.i] != 0;
+            for (long k = sv.start_serial; k < m.serial && !drop; k++)
+                if (std::abs(m.log_i[k] - q.i) <= 2 * d.wr && std::abs(m.log_j[k] - q.j) <= 2 * d.wr) drop = true;
+            if (drop && sv.done <= m.T) sv.cand = -1;
+        }
 }
 
 // add_neighbors, src/local_faldoi.cpp:679-727
@@ -109,7 +213,8 @@ void add_neighbors(Direction &d, int i, int j, int iteration, int wr)
         const float new_ener = ener * (d.sal ? d.sal[q] : 1.0f);
         if (!d.fixed[q] && new_ener < d.ene[q]) {
             d.ene[q] = ener;
-            Candidate c = { px, py, u1[q], u2[q], new_ener };
+            Candidate c = { px, py, u1[q], u2[q], new_ener, 0 };
+            spec_on_push(d, c);
             d.queue.push(c);
         }
     }
@@ -173,6 +278,7 @@ void local_growing(Direction &d, int iteration)
         d.queue.pop();
         d.pops++;
         const int p = c.j * w + c.i;
+        spec_on_pop(d, c, d.fixed[p] != 0, iteration);
         if (d.fixed[p]) continue;
         d.fixed[p] = 1;
         d.out[p] = c.u;
@@ -184,6 +290,7 @@ void local_growing(Direction &d, int iteration)
             g_trace_len += 3;
         }
         add_neighbors(d, c.i, c.j, iteration, d.wr);
+        spec_assign(d, iteration);
     }
 }
 
@@ -221,7 +328,8 @@ void insert_potential_candidates(Direction &d)                           // :813
         for (int i = 0; i < w; i++) {
             const int p = j * w + i;
             if (std::isfinite(d.out[p]) && std::isfinite(d.out[n + p])) {
-                Candidate c = { i, j, d.out[p], d.out[n + p], d.ene[p] };
+                Candidate c = { i, j, d.out[p], d.out[n + p], d.ene[p], 0 };
+                spec_on_push(d, c);
                 d.queue.push(c);
             }
         }
@@ -255,7 +363,7 @@ extern "C" void *orc_queue_new(void) { return new CandidateQueue(); }
 extern "C" void orc_queue_free(void *q) { delete (CandidateQueue *)q; }
 extern "C" void orc_queue_push(void *q, int i, int j, float u, float v, float sim)
 {
-    Candidate c = { i, j, u, v, sim };
+    Candidate c = { i, j, u, v, sim, 0 };
     ((CandidateQueue *)q)->push(c);
 }
 extern "C" int orc_queue_pop(void *q, int *i, int *j, float *u, float *v, float *sim)
@@ -455,7 +563,7 @@ extern "C" void orc_parts_get_part_frame(void *h, int part, int which, float *v)
 }
 extern "C" void orc_parts_push(void *h, int dir, int i, int j, float u, float v, float sim)
 {
-    Candidate c = { i, j, u, v, sim };
+    Candidate c = { i, j, u, v, sim, 0 };
     ((PartsHook *)h)->d[dir].queue.push(c);
 }
 extern "C" int orc_parts_image_queue_size(void *h, int dir) { return (int)((PartsHook *)h)->d[dir].queue.size(); }

@@ -373,7 +373,31 @@ def case_growing_big(rng):
     return ok, "crop %s %s %s budget=%d windows=%d" % (cr, prm, split, budget, st[1] + st[4])
 
 
-FAMILIES = {"tvl1_batch": case_tvl1_batch, "growing_big": case_growing_big, "tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv,
+def case_growing_m(rng):
+    """The other local functionals (-m 2..7): random crops (sometimes with frame pixels of either example pair), radii,
+    iteration counts, seed densities; raw RGB frames (the Lab weights need them)."""
+    method = int(rng.integers(2, 8))
+    big = method < 4                                  # the CPU checker's CSAD step sorts 97 floats per pixel-iteration
+    w, h = int(rng.integers(12, 72 if big else 44)), int(rng.integers(12, 56 if big else 34))
+    (c0, c1), cr = crop_pair(rng, w, h)
+    a_, b_ = O.preprocess_local(c0, c1)
+    go, ba = seed_flows(rng, a_, b_, float(rng.choice([0.01, 0.03, 0.1])), float(rng.choice([0, 0, 1.5])))
+    prm = dict(wr=int(rng.integers(1, 6)), loc_it=int(rng.integers(0, 3)), max_iter_patch=int(rng.integers(1, 6)),
+               fb_thresh=float(rng.choice([2.0, 0.5, 5.0])))
+    budget = int(rng.choice([16384, 257, 3000]))
+    desc = "m=%d crop %s %s seeds=%d/%d budget=%d" % (method, cr, prm, np.isfinite(go[0]).sum(), np.isfinite(ba[0]).sum(), budget)
+    want, wene, st = O.local_faldoi_raw(c0, c1, go, ba, method, **prm)
+    got, gene, gst = ctx.match_growing(c0, c1, go, ba, budget=budget, method=method, **prm)
+    ok = (util.bits_equal(got, want) and util.bits_equal(gene, wene) and list(gst.solves) == [st[1], st[4]]
+          and list(gst.pops) == [st[0], st[3]] and list(gst.fills) == [st[2], st[5]])
+    if not ok:
+        desc += " | flow: %s | energy: %s | counts device %s checker %s" % (
+            util.mismatch_report(got, want), util.mismatch_report(gene, wene),
+            [list(gst.pops), list(gst.solves), list(gst.fills)], [int(v) for v in st])
+    return ok, desc
+
+
+FAMILIES = {"growing_m": case_growing_m, "tvl1_batch": case_tvl1_batch, "growing_big": case_growing_big, "tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv,
             "growing_edge": case_growing_edge, "batch": case_batch, "batch_split": case_batch_split, "prims": case_prims, "tvl1_nan": case_tvl1_nan}
 fams = [f for f in a.family.split(",") if f]
 t_end = time.time() + a.minutes * 60

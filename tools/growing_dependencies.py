@@ -41,8 +41,19 @@ def main():
     L.orc_trace_windows.argtypes = [np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), C.c_long]
     L.orc_trace_length.restype = C.c_long
     L.orc_trace_windows(buf, cap)
+    nsolvers = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    L.orc_spec_model.argtypes = [C.c_int]
+    L.orc_spec_report.argtypes = [np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")]
+    L.orc_spec_model(nsolvers)
+    L.orc_set_num_threads(1)                     # the model observes ONE growing; keep the run single-threaded so it is the forward one
     t = time.time()
     O.local_faldoi(a, b, sd[0], sd[1])
+    if nsolvers:
+        rep = np.zeros(8)
+        L.orc_spec_report(rep)
+        print("speculation model, %d solver(s) beside the committer: %.2f G cycles instead of %.2f G (x%.2f); of %d windows: %d hits, "
+              "%d waited for, %d solved by the committer" % (nsolvers, rep[0] / 1e9, rep[1] / 1e9, rep[1] / rep[0], rep[5], rep[2], rep[4], rep[3]))
+        L.orc_spec_model(0)
     n = L.orc_trace_length() // 3
     L.orc_trace_windows(buf, 0)
     print("local step %.1f s; one growing direction minimised %d windows" % (time.time() - t, n))
@@ -59,7 +70,18 @@ def main():
             depth[y0:y1, x0:x1] = d
             hist[q] = d
             longest = max(longest, d)
-        # how far apart (in pop order) are consecutive dependent windows: the lookahead a speculative executor needs
+        dx = np.abs(np.diff(seq[:, 0])); dy = np.abs(np.diff(seq[:, 1]))
+        indep = (dx > 2 * wr) | (dy > 2 * wr)
+        # runs of consecutive windows each overlapping its predecessor: what a 2-window speculation cannot split
+        print("  iteration %d: consecutive windows that do NOT overlap: %.1f %%; adjacent (4-neighbour) successors: %.1f %%"
+              % (it, 100.0 * indep.mean(), 100.0 * ((dx + dy) == 1).mean()))
+        for look in (2, 4, 8, 16):
+            # window q is 'free' if it overlaps none of the previous `look` windows
+            free = np.ones(len(seq), bool)
+            for d in range(1, look + 1):
+                ddx = np.abs(seq[d:, 0] - seq[:-d, 0]); ddy = np.abs(seq[d:, 1] - seq[:-d, 1])
+                free[d:] &= (ddx > 2 * wr) | (ddy > 2 * wr)
+            print("     overlaps none of the previous %2d windows: %.1f %%" % (look, 100.0 * free.mean()))
         print("  iteration %d: %d windows, longest chain %d  ->  parallelism bound %.1fx" % (it, len(seq), longest, len(seq) / longest))
 
 
