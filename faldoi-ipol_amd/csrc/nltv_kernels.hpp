@@ -239,18 +239,24 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
     }
     const float wt = base[N_WT * pe + i];
     float dp = 0.0f, dq = 0.0f;
-    // non_local_divergence (:1056-1079): slot s <-> offset (k, l) in the 5x5 raster, centre skipped.  Six slots at a
-    // time: their thirty loads are issued together (clamped address for slots outside the image, result unused).
+    // non_local_divergence (:1056-1079): slot s <-> offset (k, l) in the 5x5 raster, centre skipped; the mirror of slot s is
+    // slot 23 - s at the opposite offset.  A dual plane is needed twice -- p_s[i] for slot s and p_s[i - off_s] for slot 23 - s --
+    // so the two slots of a mirror pair are loaded together (three pairs = 30 loads in flight): the second touch of a plane
+    // finds its lines in L1 / L2 instead of streaming the 48 planes through twice.  The terms are independent; the SUM keeps
+    // the reference's slot order 0..23.
+    float tp[kNlSlots], tq[kNlSlots];
+    bool oks[kNlSlots];
 #pragma unroll
-    for (int s0 = 0; s0 < kNlSlots; s0 += kNlBatch) {
+    for (int s0 = 0; s0 < kNlSlots / 2; s0 += kNlBatch / 2) {
         float w_[kNlBatch], pa[kNlBatch], pb[kNlBatch], qa[kNlBatch], qb[kNlBatch];
-        bool ok[kNlBatch];
+        int sl[kNlBatch];
 #pragma unroll
         for (int q = 0; q < kNlBatch; ++q) {
-            const int s = s0 + q, c = s < 12 ? s : s + 1;           // position in the 5x5 raster (centre = 12)
+            const int s = (q & 1) ? kNlSlots - 1 - (s0 + q / 2) : s0 + q / 2, c = s < 12 ? s : s + 1;   // s, its mirror, s+1, ...
             const int k = c / 5 - kNlR, l = c % 5 - kNlR;
-            ok[q] = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
-            const int ap = ok[q] ? i + k * nx + l : i;
+            sl[q] = s;
+            oks[s] = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
+            const int ap = oks[s] ? i + k * nx + l : i;
             const int rp = kNlSlots - 1 - s;
             w_[q] = base[(size_t)(N_W + s) * pe + i];
             pa[q] = base[(size_t)(N_P + s) * pe + i];
@@ -260,10 +266,15 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
         }
 #pragma unroll
         for (int q = 0; q < kNlBatch; ++q) {
-            const float tp = dp + w_[q] * (pa[q] - pb[q]), tq = dq + w_[q] * (qa[q] - qb[q]);
-            dp = ok[q] ? tp : dp;
-            dq = ok[q] ? tq : dq;
+            tp[sl[q]] = w_[q] * (pa[q] - pb[q]);
+            tq[sl[q]] = w_[q] * (qa[q] - qb[q]);
         }
+    }
+#pragma unroll
+    for (int s = 0; s < kNlSlots; ++s) {
+        const float np = dp + tp[s], nq = dq + tq[s];
+        dp = oks[s] ? np : dp;
+        dq = oks[s] ? nq : dq;
     }
     dp /= wt;
     dq /= wt;
