@@ -190,21 +190,31 @@ def main():
     per_rank = F.shard.gather_scalars(px_iters_local / dt / 1e6, dist if use_dist else None, dev)
 
     # Durations of the two kernels of a step (outside the timed region), from whole-solve HIP-event times on the
-    # library's own stream: the per-warp kernel is idempotent, so a solve that launches it twice per warp
-    # (FALDOI_WARP_REPEAT=2) returns the same bits and takes exactly `warps` warp-kernel durations longer.
-    #   warp_us = (T2 - T1) / warps ;  chunk_us = (T1 - warps * warp_us - setup) / chunk launches
-    # No event sits between kernels (an event pair around every launch inflated it by ~7 % in round 1).
+    # library's own stream.  Both kernels can be launched twice in a row without changing a bit: the per-warp kernel only
+    # writes the warp constants (FALDOI_WARP_REPEAT=2), the fused iteration kernel reads one state buffer and writes the
+    # other (FALDOI_CHUNK_REPEAT=2).  The difference of two whole-solve times is then the marginal cost of ONE more launch of
+    # that kernel in the real stream: its duration plus the gap to the next launch.  (No event sits between kernels: an
+    # event pair around every launch inflated the kernel by ~7 % in round 1.  rocprofv3's kernel-trace durations,
+    # profiles/r02_counters.json, exclude the gap but carry ~1 us of tracing overhead on kernels this short.)
     kern = None
     if rank == 0:
         reps = max(3, min(args.steps, 10))
-        t1 = min(step()[2] for _ in range(reps))
-        os.environ["FALDOI_WARP_REPEAT"] = "2"
-        t2 = min(step()[2] for _ in range(reps))
-        os.environ["FALDOI_WARP_REPEAT"] = "1"
-        nl1 = batch.last_timing()[1]
-        warp_us = max(0.0, (t2 - t1) * 1e3 / WARPS)
-        chunk_us = (t1 * 1e3 - WARPS * warp_us) / nl1
-        kern = dict(chunk_us=chunk_us, warp_us=warp_us, solve_ms=t1, launches=nl1, schedule=batch.last_schedule())
+
+        def best(env):
+            for k_, v_ in env.items():
+                os.environ[k_] = v_
+            t = min(step()[2] for _ in range(reps))
+            for k_ in env:
+                os.environ[k_] = "1"
+            return t
+        t1 = best({})
+        t2w = best({"FALDOI_WARP_REPEAT": "2"})
+        t2c = best({"FALDOI_CHUNK_REPEAT": "2"})
+        nl1 = batch.last_timing()[1]                      # logical launches (a repeated launch counts once)
+        warp_us = max(0.0, (t2w - t1) * 1e3 / WARPS)
+        chunk_us = max(0.0, (t2c - t1) * 1e3 / nl1)
+        kern = dict(chunk_us=chunk_us, warp_us=warp_us, solve_ms=t1, launches=nl1, schedule=batch.last_schedule(),
+                    other_us_per_launch=(t1 * 1e3 - WARPS * warp_us - nl1 * chunk_us) / nl1)
 
     out = None
     if rank == 0:
@@ -257,8 +267,8 @@ def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, dev_
             "frac": round(valu / (chunk_us * 1e-6) / 1e9 / VALU_PEAK_GINSTR, 4) if valu else None,
             "traffic": traffic,
             "launch_us": round(chunk_us, 2),
-            "launch_us_source": "HIP events around whole solves on the library's stream; solve(warp kernel x2) - solve = "
-                                "warps x warp kernel; the rest / chunk launches",
+            "launch_us_source": "HIP events around whole solves on the library's stream: solve(every launch of this kernel "
+                                "issued twice) - solve, per launch = kernel duration + launch gap",
             "launch_us_rocprof": ck.get("avg_us") if same else None,
             "valu_instr_per_launch": valu, "valu_instr_per_useful_px_iter":
                 round(valu * 64 / (px * iters_per_launch), 1) if valu else None,

@@ -474,6 +474,8 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     const dim3 wgrid(((npix + 255) / 256) * b->npairs);
     int wvariant = 4;                                  // waves/SIMD the per-warp kernel is compiled for
     if (const char *v = getenv("FALDOI_WARP_WPS")) wvariant = atoi(v);
+    int chunk_repeat = 1;
+    if (const char *v = getenv("FALDOI_CHUNK_REPEAT")) { const int r = atoi(v); if (r >= 1 && r <= 8) chunk_repeat = r; }
     int warp_repeat = 1;
     if (const char *v = getenv("FALDOI_WARP_REPEAT")) { const int r = atoi(v); if (r >= 1 && r <= 8) warp_repeat = r; }
     int launches = 0;
@@ -529,9 +531,12 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
                     HIP_TRY(hipGetLastError());
                 }
                 if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
-                HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
-                                     b->ctl, b->err_part, 1, cur, (n == 0 ? 1 : 0) | (n + it >= prm->max_inner ? 2 : 0), it, w,
-                                     (d_stamps && w == warps / 2 && n == 0) ? d_stamps : nullptr));
+                // FALDOI_CHUNK_REPEAT=r (measurement aid, like FALDOI_WARP_REPEAT): a launch reads one state buffer and writes
+                // the other, so repeating it with the same arguments rewrites the same values
+                for (int r = 0; r < chunk_repeat; ++r)
+                    HIP_TRY(launch_chunk(tc, grid, s, b->slabs, b->plane_elems, b->nx, b->ny, ntx, nty, b->npairs, halo, k,
+                                         b->ctl, b->err_part, 1, cur, (n == 0 ? 1 : 0) | (n + it >= prm->max_inner ? 2 : 0), it, w,
+                                         (d_stamps && w == warps / 2 && n == 0) ? d_stamps : nullptr));
                 if (ev_timing) HIP_TRY(hipEventRecord(b->ev[ev_used++], s));
                 ++launches;
                 cur ^= 1;

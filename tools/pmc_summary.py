@@ -40,8 +40,12 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--label", default="")
     ap.add_argument("--chunk-tile", default="", help="R,NW,chunk,pairs,W,H of the chunk kernel's schedule in these runs")
+    ap.add_argument("--grid", action="append", default=[], metavar="FAMILY=THREADS",
+                    help="count only the dispatches of FAMILY whose grid has THREADS work-items (the bench's secondary legs launch the "
+                         "same kernels on other sizes)")
     ap.add_argument("dirs", nargs="+")
     a = ap.parse_args()
+    want_grid = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.grid}
     acc = {}                                      # family -> counter -> [sum, count]
     meta = {}
     pmc_passes = 0
@@ -53,7 +57,7 @@ def main():
             with open(path, newline="") as f:
                 for row in csv.DictReader(f):
                     fam = family(row["Kernel_Name"])
-                    if not fam:
+                    if not fam or (fam in want_grid and int(row["Grid_Size"]) != want_grid[fam]):
                         continue
                     s = acc.setdefault(fam, {}).setdefault(row["Counter_Name"], [0.0, 0])
                     s[0] += float(row["Counter_Value"])
@@ -69,7 +73,8 @@ def main():
                 with open(path, newline="") as f:
                     for row in csv.DictReader(f):
                         fam = family(row["Kernel_Name"])
-                        if not fam:
+                        grid = int(row["Grid_Size_X"]) * int(row["Grid_Size_Y"]) * int(row["Grid_Size_Z"])
+                        if not fam or (fam in want_grid and grid != want_grid[fam]):
                             continue
                         s = acc.setdefault(fam, {}).setdefault("_dur_ns", [0.0, 0])
                         s[0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
