@@ -21,7 +21,7 @@ EXPORTS = [
     "faldoi_ctx_synchronize", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
     "faldoi_tvl1_batch_create", "faldoi_tvl1_batch_destroy", "faldoi_tvl1_batch_upload",
     "faldoi_tvl1_batch_reset", "faldoi_tvl1_batch_solve", "faldoi_tvl1_batch_download",
-    "faldoi_tvl1_batch_last_timing", "faldoi_tvl1_batch_last_schedule", "faldoi_centered_gradient", "faldoi_forward_gradient",
+    "faldoi_tvl1_batch_last_timing", "faldoi_tvl1_batch_last_schedule", "faldoi_tvl1_batch_last_persistent", "faldoi_centered_gradient", "faldoi_forward_gradient",
     "faldoi_divergence", "faldoi_bicubic_warp", "faldoi_selftest_division",
     "faldoi_preprocess_global", "faldoi_tvl1_batch_upload_images",
     "faldoi_nltvcsad_default_params", "faldoi_nltvcsad_global", "faldoi_image_to_lab",
@@ -113,6 +113,7 @@ def lib():
     L.faldoi_tvl1_batch_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                                 C.POINTER(C.c_long), C.POINTER(C.c_double)]
     L.faldoi_tvl1_batch_last_schedule.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.faldoi_tvl1_batch_last_persistent.argtypes = [vp, C.POINTER(C.c_int)]
     L.faldoi_centered_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_forward_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_divergence.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
@@ -459,6 +460,12 @@ class Tvl1Batch:
         r, nw, k = C.c_int(), C.c_int(), C.c_int()
         _check(lib().faldoi_tvl1_batch_last_schedule(self._h, C.byref(r), C.byref(nw), C.byref(k)))
         return r.value, nw.value, k.value
+
+    def last_persistent(self):
+        """True when the last solve ran as one launch of the persistent kernel."""
+        v = C.c_int()
+        _check(lib().faldoi_tvl1_batch_last_persistent(self._h, C.byref(v)))
+        return bool(v.value)
 
     def download(self, pair, want_xi=False):
         u = np.empty((2, self.h, self.w), np.float32)

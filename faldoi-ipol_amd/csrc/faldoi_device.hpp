@@ -12,7 +12,17 @@
 
 #pragma clang fp contract(off)
 
+// FALDOI_WHATIF (tools/whatif_probe.py, never defined in the product build): timing-only builds with one ingredient removed
+// -- wrong results, same instruction stream otherwise -- to see what a kernel's time is made of.
+//   1 no workgroup barriers inside an iteration   2 the duals' quotient path never taken   4 threshold quotient -> product
+//   8 primal quotients by theta -> products       16 no waiting for the neighbours           32 no warp constants
+#ifndef FALDOI_WHATIF
+#define FALDOI_WHATIF 0
+#endif
+
 namespace faldoi {
+
+constexpr int kWhatIf = FALDOI_WHATIF;
 
 // Smallest float that is NOT below the reference's double threshold GRAD_IS_ZERO = 1E-8
 // (src/parameters.h:45): for float g, ((double)g < 1E-8) == (g < kGradZeroF).
@@ -277,7 +287,7 @@ __device__ __forceinline__ void threshold_step(float rho_c, float I1wx, float I1
     const float lg = l_t * grad;
     const bool below = rho < -lg;                 // (-l_t)*grad == -(l_t*grad) exactly
     const bool above = rho > lg;
-    const float fi = div_by(-rho, grad, rgrad);
+    const float fi = (kWhatIf & 4) ? -rho * (float)rgrad : div_by(-rho, grad, rgrad);
     const float f = below ? l_t : (above ? -l_t : fi);
     float d1 = f * I1wx;
     float d2 = f * I1wy;
@@ -309,7 +319,7 @@ __device__ __forceinline__ void dual_step(float &xi11, float &xi12, float &xi21,
     // returns the same bits for the g <= 1 lanes.  NaN g (a NaN dual: windows over pruned, unfilled flow): the
     // reference's MAX(1, xi_N) is (1 > xi_N) ? 1 : xi_N, i.e. NaN, and all four duals of the pixel become NaN, not
     // only the NaN ones -- so the tests are written as "not g <= 1" and a NaN g takes the general path as NaN.
-    if (__builtin_amdgcn_ballot_w64(!(g <= 1.0f)) != 0ull) {
+    if (!(kWhatIf & 2) && __builtin_amdgcn_ballot_w64(!(g <= 1.0f)) != 0ull) {
         // max(1, sqrt(g)) == sqrt(max(1, g)): sqrt is monotone and sqrt(1) == 1 exactly
         const float n = sqrt_ge1((g <= 1.0f) ? 1.0f : g);
         const double rn = recip_f64(n);             // one reciprocal, four exact quotients
@@ -328,8 +338,10 @@ __device__ __forceinline__ float primal_step(float &u1, float &u2, float &ub1, f
                                              float theta, double rtheta, float tau)
 {
     const float u1k = u1, u2k = u2;
-    const float n1 = u1k - tau * (-div1 + div_by(u1k - v1, theta, rtheta));
-    const float n2 = u2k - tau * (-div2 + div_by(u2k - v2, theta, rtheta));
+    const float q1 = (kWhatIf & 8) ? (u1k - v1) * (float)rtheta : div_by(u1k - v1, theta, rtheta);
+    const float q2 = (kWhatIf & 8) ? (u2k - v2) * (float)rtheta : div_by(u2k - v2, theta, rtheta);
+    const float n1 = u1k - tau * (-div1 + q1);
+    const float n2 = u2k - tau * (-div2 + q2);
     const float e = (n1 - u1k) * (n1 - u1k) + (n2 - u2k) * (n2 - u2k);
     u1 = n1;
     u2 = n2;

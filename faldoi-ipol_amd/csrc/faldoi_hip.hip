@@ -5,6 +5,7 @@
 // entry point either launches HIP kernels or fails with a status code.
 #include "faldoi_hip.h"
 #include "tvl1_kernels.hpp"
+#include "tvl1_persist_kernel.hpp"
 #include "preprocess_kernels.hpp"
 #include "nltv_kernels.hpp"
 #include "local_kernels.hpp"
@@ -137,6 +138,12 @@ struct faldoi_tvl1_batch {
     int last_tile_r = 0, last_tile_nw = 0, last_chunk = 0;   // schedule of the last solve
     long last_px_iters = 0;
     std::vector<hipEvent_t> ev;       // per-launch event pairs (only when FALDOI_EVENT_TIMING=1)
+    float *xslab = nullptr;           // halo exchange slabs of the persistent kernel (tvl1_persist_kernel.hpp)
+    size_t xslab_bytes = 0;
+    unsigned *xflags = nullptr;       // its epoch flags + abort word
+    size_t xflags_bytes = 0;
+    int last_persistent = 0;
+    bool persist_off = false;         // the persistent kernel once gave up on this batch (its workgroups were not all resident)
 };
 
 static int check_device(int *count)
@@ -304,6 +311,73 @@ static void launch_warp(int variant, dim3 grid, hipStream_t s, float *base, size
         hipLaunchKernelGGL(tvl1_warp_kernel<4>, grid, dim3(256), lds, s, base, pe, nx, ny, npairs, ctl, st, cur);
 }
 
+// The persistent kernel (tvl1_persist_kernel.hpp) runs a static schedule of ONE pair whose tiles fit the chip one per CU.
+// Geometry: tile = 64 x R*NW, k iterations between two halo exchanges, halo k columns and hy = k rounded up to a multiple of R
+// rows (a thread's R rows travel as one 16-byte vector and must share their owner).
+struct PersistCfg {
+    int R, NW, k, hy;
+};
+
+static bool persist_supported(int r, int w)
+{
+    return (r == 4 && (w == 16 || w == 13 || w == 11)) || (r == 3 && (w == 16 || w == 14));
+}
+
+static bool persist_fits(const faldoi_tvl1_batch *b, int R, int NW, int k, PersistCfg *out)
+{
+    if (k < 1 || k > kMaxChunk) return false;
+    const int hy = ((k + R - 1) / R) * R;
+    const int Sx = kTileW - 2 * k, Sy = R * NW - 2 * hy;
+    if (Sx < k || Sy < hy || Sx < 8 || Sy < R) return false;            // a halo reaches the adjacent tile only
+    const long tiles = (long)((b->nx + Sx - 1) / Sx) * ((b->ny + Sy - 1) / Sy);
+    if (tiles > b->ctx->n_cu) return false;                               // every workgroup resident, one per CU
+    *out = PersistCfg{ R, NW, k, hy };
+    return true;
+}
+
+static bool pick_persist(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, PersistCfg *out)
+{
+    if (const char *on = getenv("FALDOI_PERSIST"))                        // FALDOI_PERSIST=0: always the per-launch path
+        if (atoi(on) <= 0) return false;
+    if (b->persist_off) return false;                                     // a launch of this batch timed out before
+    if (prm->tol_stop != 0 || b->npairs != 1) return false;
+    if (const char *s = getenv("FALDOI_PERSIST_CFG")) {                   // tuning aid: R,NW,k
+        int r = 0, w = 0, k = 0;
+        if (sscanf(s, "%d,%d,%d", &r, &w, &k) == 3 && persist_supported(r, w)) {
+            if (k > prm->max_inner) k = prm->max_inner;
+            return persist_fits(b, r, w, k, out);
+        }
+        return false;
+    }
+    // 64 x 48 tiles (three rows per thread), five iterations between exchanges: the fastest of the geometries tried at
+    // 1024x436 (tools/persist_probe.py sweep), and the only one faster than the per-launch path there; an explicit
+    // params.chunk is honoured where a geometry fits it
+    static const int cand[][3] = { { 3, 16, 5 }, { 4, 16, 8 } };
+    for (const auto &c : cand) {
+        int k = prm->chunk ? prm->chunk : c[2];
+        if (k > prm->max_inner) k = prm->max_inner;
+        if (persist_fits(b, c[0], c[1], k, out)) return true;
+        if (!prm->chunk) break;
+    }
+    return false;
+}
+
+static hipError_t launch_persist(const PersistCfg &pc, dim3 grid, hipStream_t s, const PersistArgs &a)
+{
+#define FALDOI_CASE(r, w)                                                                          \
+    if (pc.R == r && pc.NW == w) {                                                                 \
+        hipLaunchKernelGGL((tvl1_persist_kernel<r, w>), grid, dim3(64 * w), 0, s, a);              \
+        return hipGetLastError();                                                                  \
+    }
+    FALDOI_CASE(3, 16)
+    FALDOI_CASE(3, 14)
+    FALDOI_CASE(4, 16)
+    FALDOI_CASE(4, 13)
+    FALDOI_CASE(4, 11)
+#undef FALDOI_CASE
+    return hipErrorInvalidValue;
+}
+
 // ------------------------------------------------------------------------------------------ batch
 static int faldoi_tvl1_batch_create_impl(faldoi_ctx *ctx, int npairs, int nx, int ny, faldoi_tvl1_batch **out)
 {
@@ -353,6 +427,8 @@ extern "C" void faldoi_tvl1_batch_destroy(faldoi_tvl1_batch *b)
     if (b->d_iters) (void)hipFree(b->d_iters);
     if (b->d_err) (void)hipFree(b->d_err);
     if (b->d_done) (void)hipFree(b->d_done);
+    if (b->xslab) (void)hipFree(b->xslab);
+    if (b->xflags) (void)hipFree(b->xflags);
     delete b;
 }
 
@@ -430,9 +506,15 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     TileCfg tc;
     int chunk;
     pick_schedule(b, prm, &tc, &chunk);
+    PersistCfg pc{ 0, 0, 0, 0 };
+    const bool persist = pick_persist(b, prm, &pc);
+    if (persist) {
+        tc = TileCfg{ pc.R, pc.NW };
+        chunk = pc.k;
+    }
     const int TH = tc.R * tc.NW;
     const int halo = chunk;
-    const int Sx = kTileW - 2 * halo, Sy = TH - 2 * halo;
+    const int Sx = kTileW - 2 * halo, Sy = TH - 2 * (persist ? pc.hy : halo);
     const int ntx = (b->nx + Sx - 1) / Sx, nty = (b->ny + Sy - 1) / Sy;
     const int ntiles = ntx * nty;
     const int total_tiles = ntiles * b->npairs;
@@ -510,12 +592,59 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     // its loads had landed, when its iterations ended and when its stores had drained (constant 100 MHz clock)
     unsigned long long *d_stamps = nullptr;
     DevBuf stamp_buf;
-    if (!dynamic && getenv("FALDOI_STAMPS") && atoi(getenv("FALDOI_STAMPS")) > 0) {
+    if (!dynamic && !persist && getenv("FALDOI_STAMPS") && atoi(getenv("FALDOI_STAMPS")) > 0) {
         HIP_TRY(hipMalloc((void **)&stamp_buf.p, sizeof(unsigned long long) * 4 * grid.x));
         d_stamps = reinterpret_cast<unsigned long long *>(stamp_buf.p);
         HIP_TRY(hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * 4 * grid.x, s));
     }
-    if (!dynamic) {
+    unsigned long long *p_stamps_out = nullptr;
+    if (persist) {
+        const size_t slab_bytes = 2ull * ntiles * kXPlanes * tc.NW * kTileW * 16ull;
+        const size_t flag_bytes = ((size_t)ntiles + 1) * kFlagStride * sizeof(unsigned);
+        if (slab_bytes >= (1ull << 32)) return fail(FALDOI_ERR_STATE, "exchange slab of %zu bytes", slab_bytes);
+        int rc = ensure((void **)&b->xslab, &b->xslab_bytes, slab_bytes);
+        if (rc) return rc;
+        rc = ensure((void **)&b->xflags, &b->xflags_bytes, flag_bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(b->xflags, 0, flag_bytes, s));      // epochs count from 0 in every launch
+        unsigned long long *p_stamps = nullptr;
+        if (getenv("FALDOI_STAMPS") && atoi(getenv("FALDOI_STAMPS")) > 0) {
+            HIP_TRY(hipMalloc((void **)&stamp_buf.p, sizeof(unsigned long long) * kPersistStamps * ntiles));
+            p_stamps = reinterpret_cast<unsigned long long *>(stamp_buf.p);
+            HIP_TRY(hipMemsetAsync(p_stamps, 0, sizeof(unsigned long long) * kPersistStamps * ntiles, s));
+        }
+        PersistArgs a;
+        a.base = b->slabs;
+        a.plane_elems = b->plane_elems;
+        a.nx = b->nx; a.ny = b->ny; a.ntx = ntx; a.nty = nty;
+        a.hx = chunk; a.hy = pc.hy;
+        a.prm = k;
+        a.err_out = b->err_part;
+        a.xslab = b->xslab;
+        a.xslab_bytes = (unsigned)slab_bytes;
+        a.flags = b->xflags;
+        a.spin_limit = 400000u;                                    // ~0.5 s of polling: a lost workgroup, not a slow one
+        if (const char *v = getenv("FALDOI_PERSIST_SPINS")) { const long q = atol(v); if (q > 0 && q < (1L << 31)) a.spin_limit = (unsigned)q; }
+        a.stamps = p_stamps;
+        a.stamp_warp = warps / 2;
+        while (b->ev.size() < 2) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            b->ev.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(b->ev[0], s));
+        HIP_TRY(launch_persist(pc, grid, s, a));
+        HIP_TRY(hipEventRecord(b->ev[1], s));
+        ev_used = 2;
+        launches = 1;
+        const int rem = prm->max_inner % chunk;
+        hipLaunchKernelGGL(tvl1_static_stats_kernel, dim3(warps * b->npairs), dim3(256), 0, s, b->err_part, ntiles,
+                           b->npairs, warps, prm->max_inner, rem ? rem : chunk, b->d_iters, b->d_err);
+        HIP_TRY(hipGetLastError());
+        b->final_cur[0] = 1;
+        HIP_TRY(hipMemcpyAsync(c->h_done, b->xflags + (size_t)ntiles * kFlagStride, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        p_stamps_out = p_stamps;
+    } else if (!dynamic) {
         int cur = 0;
         int last_iters = chunk;
         for (int w = 0; w < warps; ++w) {
@@ -584,6 +713,40 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         chunk_ms += t;
     }
 
+    if (persist && *c->h_done != 0) {
+        // Bounded spins: a tile that waited ~0.5 s for a neighbour raised the abort word and every workgroup left.  The cause is
+        // residency (another kernel held CUs this grid needed), not the data: run this batch on the per-launch path from now on.
+        static std::atomic<bool> told{ false };
+        if (!told.exchange(true))
+            fprintf(stderr, "faldoi: the persistent TV-L1 kernel gave up waiting for a neighbouring tile (first at tile %d): its "
+                            "workgroups were not all resident; using the per-launch path\n", *c->h_done - 1);
+        b->persist_off = true;
+        return faldoi_tvl1_batch_solve_impl(b, prm, stats);
+    }
+    if (p_stamps_out) {
+        std::vector<unsigned long long> hs((size_t)kPersistStamps * ntiles);
+        HIP_TRY(hipMemcpy(hs.data(), p_stamps_out, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
+        // stamp slots: 0 warp start | 7 a middle wave's ring stores drained | 2 barrier passed, flag stored | 3 neighbours ready |
+        // 4 halo landed | 5 first chunk iterated | 12, 8, 9, 10, 11 the same for the last exchange of the warp | 6 warp done
+        static const int order[] = { 0, 1, 7, 2, 3, 4, 5, 12, 8, 9, 10, 11, 6 };
+        static const char *name[] = { "", "warp constants", "ring stored and drained", "barrier, flag", "neighbours ready", "halo landed",
+                                      "chunk iterated", "ring stored and drained", "barrier, flag", "neighbours ready", "halo landed",
+                                      "chunk iterated", "(end of warp)" };
+        fprintf(stderr, "faldoi persistent stamps, warp %d, %d tiles; us since the previous stamp, mean / max over the tiles:\n", warps / 2, ntiles);
+        for (int j = 1; j < 13; ++j) {
+            double sum = 0, mx = 0;
+            int cnt = 0;
+            for (int q = 0; q < ntiles; ++q) {
+                const unsigned long long t1 = hs[(size_t)kPersistStamps * q + order[j]], t0 = hs[(size_t)kPersistStamps * q + order[j - 1]];
+                if (!t1 || !t0) continue;
+                const double us = ((double)t1 - (double)t0) * 0.01;
+                sum += us;
+                if (us > mx) mx = us;
+                ++cnt;
+            }
+            if (cnt) fprintf(stderr, "   %-42s %6.2f / %6.2f\n", name[j], sum / cnt, mx);
+        }
+    }
     if (d_stamps) {
         std::vector<unsigned long long> hs((size_t)4 * total_tiles);
         HIP_TRY(hipMemcpy(hs.data(), d_stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
@@ -638,6 +801,7 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     b->last_tile_r = tc.R;
     b->last_tile_nw = tc.NW;
     b->last_chunk = chunk;
+    b->last_persistent = persist ? 1 : 0;
     b->last_px_iters = px_iters;
     return FALDOI_OK;
 }
@@ -656,6 +820,14 @@ extern "C" int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve
     if (chunk_launches) *chunk_launches = b->last_launches;
     if (px_iters) *px_iters = b->last_px_iters;
     if (chunk_kernel_ms) *chunk_kernel_ms = b->last_chunk_ms;
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_tvl1_batch_last_persistent(faldoi_tvl1_batch *b, int *persistent)
+{
+    if (!b || !persistent) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    if (!b->solved) return fail(FALDOI_ERR_STATE, "no solve has completed");
+    *persistent = b->last_persistent;
     return FALDOI_OK;
 }
 

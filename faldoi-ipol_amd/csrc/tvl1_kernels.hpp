@@ -288,11 +288,139 @@ __global__ __launch_bounds__(256, WPS) void tvl1_warp_kernel(float *__restrict__
 // BORDER = false is the specialisation for tiles whose 64 x TH footprint contains no pixel of
 // the image frame (first/last row or column): every stencil uses the interior formula, no
 // per-pixel class selects.  Chosen per workgroup (uniform branch) by the kernel below.
+// The register-resident state of one thread: R rows of its column.
+template <int R>
+struct TileState {
+    float u1[R], u2[R], ub1[R], ub2[R], x11[R], x12[R], x21[R], x22[R];   // flow, over-relaxed flow, duals
+    float rc[R], ix[R], iy[R], gr[R];                                      // warp constants, |grad I|^2
+    double rgr[R];                                                         // fp64 reciprocal of gr, constant over a warp
+    bool own[R];                                                           // pixel stored by this tile
+};
+
+// `iters` primal-dual iterations (src/global_faldoi.cpp:684-783) on the tile held in `s`; shared by the per-launch kernel
+// below and by the persistent kernel (tvl1_persist_kernel.hpp).  halo_y = rows of halo above and below the owned rows; the
+// caller has put row 0 of every wave's ubar into s_ub1 / s_ub2 and zeroed s_err[0..iters).  Per-lane maxima of |du|^2 over
+// the owned pixels are left in s_err[it][lane].
+//
+// track_from: iterations it >= track_from record max |du|^2; the others skip it (a static schedule only ever reads the
+// last iteration of a warp; the primal step is compiled twice, with and without the bookkeeping).
+template <int R, int NW, int BORDER, bool TRACK>
+__device__ __forceinline__ void tvl1_one_iteration(TileState<R> &s, int it, int iters, int halo_y, int gx, int gy0, int nx,
+                                                   int ny, int lane, int wv, bool wave_live, const TvConst &prm,
+                                                   float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
+                                                   float (*s_x22)[kTileW], unsigned (*s_err)[kTileW])
+{
+    constexpr int TH = R * NW;
+    // BORDER bit 0: the tile footprint contains image column 0 or nx-1; bit 1: row 0 or ny-1.  A tile on the left or right
+    // edge only (most border tiles) keeps the row formulas of the interior, and vice versa.
+    constexpr bool COLB = (BORDER & 1) != 0, ROWB = (BORDER & 2) != 0;
+    const bool last_c = COLB && (gx == nx - 1);
+    const bool first_c = COLB && (gx == 0);
+
+    {
+        // Rows whose values can still reach the owned rows [halo_y, TH-halo_y) before the launch ends:
+        // after this iteration u is needed on tile rows [need_lo, need_hi), the new duals one row
+        // further up (the divergence reads xi12/xi22 of the row above).  Everything else is skipped
+        // (scalar tests: tile row = wv*R + r is wave-uniform).
+        const int reach = iters - 1 - it;
+        const int need_lo = halo_y - reach, need_hi = TH - halo_y + reach;
+        if (!(kWhatIf & 1)) __syncthreads();                   // ubar row 0 of every wave visible
+        // ---- dual step: forward gradient of ubar (:725-726) + ofTVl2_getD (:735) ----
+        if (wave_live && wv * R + R > need_lo - 1 && wv * R < need_hi) {
+            const float dn1 = (wv < NW - 1) ? s_ub1[wv < NW - 1 ? wv + 1 : wv][lane] : 0.0f;
+            const float dn2 = (wv < NW - 1) ? s_ub2[wv < NW - 1 ? wv + 1 : wv][lane] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (wv * R + r < need_lo - 1 || wv * R + r >= need_hi) continue;
+                // neighbours are fetched inside the executed block so the DPP moves fold into the
+                // subtractions (v_sub_f32_dpp)
+                const float r1 = lane_right(s.ub1[r]);
+                const float r2 = lane_right(s.ub2[r]);
+                const float d1 = (r < R - 1) ? s.ub1[r < R - 1 ? r + 1 : r] : dn1;
+                const float d2 = (r < R - 1) ? s.ub2[r < R - 1 ? r + 1 : r] : dn2;
+                const bool last_r = ROWB && (gy0 + r == ny - 1);
+                dual_step(s.x11[r], s.x12[r], s.x21[r], s.x22[r],
+                          fwd_diff(r1, s.ub1[r], last_c), fwd_diff(d1, s.ub1[r], last_r),
+                          fwd_diff(r2, s.ub2[r], last_c), fwd_diff(d2, s.ub2[r], last_r), prm.tau);
+            }
+            s_x12[wv][lane] = s.x12[R - 1];
+            s_x22[wv][lane] = s.x22[R - 1];
+        }
+        if (!(kWhatIf & 1)) __syncthreads();                   // new duals' last rows visible
+        // ---- primal step: divergence (:745-746), TH (:690-718), getP (:770), relax (:780) ----
+        if (wave_live && wv * R + R > need_lo && wv * R < need_hi) {
+            const float up12 = (wv > 0) ? s_x12[wv > 0 ? wv - 1 : 0][lane] : 0.0f;
+            const float up22 = (wv > 0) ? s_x22[wv > 0 ? wv - 1 : 0][lane] : 0.0f;
+            float emax = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int gy = gy0 + r;
+                if (wv * R + r < need_lo || wv * R + r >= need_hi) continue;
+                const float l11 = lane_left(s.x11[r]);
+                const float l21 = lane_left(s.x21[r]);
+                const float t12 = (r > 0) ? s.x12[r > 0 ? r - 1 : 0] : up12;
+                const float t22 = (r > 0) ? s.x22[r > 0 ? r - 1 : 0] : up22;
+                float div1, div2;
+                if (BORDER) {
+                    const PixClass pc{ first_c, last_c, ROWB && gy == 0, ROWB && gy == ny - 1 };
+                    div1 = div_sample(s.x11[r], l11, s.x12[r], t12, pc);
+                    div2 = div_sample(s.x21[r], l21, s.x22[r], t22, pc);
+                } else {                                       // src/utils.cpp:250-256
+                    div1 = (s.x11[r] - l11) + (s.x12[r] - t12);
+                    div2 = (s.x21[r] - l21) + (s.x22[r] - t22);
+                }
+                float v1, v2;
+                threshold_step(s.rc[r], s.ix[r], s.iy[r], s.gr[r], s.rgr[r], s.u1[r], s.u2[r], prm.l_t, v1, v2);
+                const float e = primal_step(s.u1[r], s.u2[r], s.ub1[r], s.ub2[r], v1, v2, div1, div2, prm.theta,
+                                            prm.rtheta, prm.tau);
+                if (TRACK) emax = (s.own[r] && e > emax) ? e : emax;
+            }
+            s_ub1[wv][lane] = s.ub1[0];
+            s_ub2[wv][lane] = s.ub2[0];
+            // per-lane running maximum of this iteration (values >= 0: uint order == float order;
+            // max is order-independent => deterministic); reduced across lanes once, at the end
+            if (TRACK) atomicMax(&s_err[it][lane], __float_as_uint(emax));
+        }
+    }
+}
+
+template <int R, int NW, int BORDER>
+__device__ __forceinline__ void tvl1_iterate(TileState<R> &s, int iters, int track_from, int halo_y, int gx, int gy0, int nx,
+                                             int ny, int lane, int wv, bool wave_live, const TvConst &prm,
+                                             float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
+                                             float (*s_x22)[kTileW], unsigned (*s_err)[kTileW])
+{
+    for (int it = 0; it < iters; ++it) {
+        if (it >= track_from)
+            tvl1_one_iteration<R, NW, BORDER, true>(s, it, iters, halo_y, gx, gy0, nx, ny, lane, wv, wave_live, prm, s_ub1, s_ub2,
+                                                    s_x12, s_x22, s_err);
+        else
+            tvl1_one_iteration<R, NW, BORDER, false>(s, it, iters, halo_y, gx, gy0, nx, ny, lane, wv, wave_live, prm, s_ub1, s_ub2,
+                                                     s_x12, s_x22, s_err);
+    }
+}
+
+// Wave i reduces iteration i's 64 per-lane maxima and stores them (plain stores, read by the next kernel of the stream).
+template <int NW>
+__device__ __forceinline__ void tvl1_store_errors(unsigned (*s_err)[kTileW], int iters, int lane, int wv,
+                                                  float *__restrict__ err_slot_base)
+{
+    for (int i = wv; i < kMaxChunk; i += NW) {
+        float m = (i < iters) ? __uint_as_float(s_err[i][lane]) : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(m, o);
+            m = other > m ? other : m;
+        }
+        if (lane == 0) err_slot_base[i] = m;
+    }
+}
+
 template <int R, int NW, int BORDER>
 __device__ __forceinline__ void tvl1_chunk_body(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int npairs, int ntiles, int t,
     int pair, int txi, int tyi, int halo, const TvConst &prm, float *__restrict__ err_out,
-    int cur, int first /* bit 0: starts a warp, bit 1: ends one */, int iters, int err_slot,
+    int cur, int first /* bit 0: starts a warp, bit 1: ends one */, int iters, int track_from, int err_slot,
     float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW], float (*s_x22)[kTileW],
     unsigned (*s_err)[kTileW], unsigned long long *stamps)
 {
@@ -314,140 +442,70 @@ __device__ __forceinline__ void tvl1_chunk_body(
     const float *iwxp = slab + (size_t)P_IWX * plane_elems;
     const float *iwyp = slab + (size_t)P_IWY * plane_elems;
 
-    float u1[R], u2[R], ub1[R], ub2[R], x11[R], x12[R], x21[R], x22[R], rc[R], ix[R], iy[R], gr[R];
-    double rgr[R];                               // fp64 reciprocal of |grad I|^2, constant over the launch
-    bool in[R], own[R];
+    TileState<R> s;
+    bool in[R];
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int gy = gy0 + r;
         in[r] = col_in && gy >= 0 && gy < ny;
-        own[r] = in[r] && col_own && gy >= tyi * Sy && gy < (tyi + 1) * Sy;
+        s.own[r] = in[r] && col_own && gy >= tyi * Sy && gy < (tyi + 1) * Sy;
         const int p = in[r] ? gy * nx + gx : 0;
-        u1[r] = in[r] ? src[0 * plane_elems + p] : 0.0f;
-        u2[r] = in[r] ? src[1 * plane_elems + p] : 0.0f;
-        x11[r] = in[r] ? src[4 * plane_elems + p] : 0.0f;
-        x12[r] = in[r] ? src[5 * plane_elems + p] : 0.0f;
-        x21[r] = in[r] ? src[6 * plane_elems + p] : 0.0f;
-        x22[r] = in[r] ? src[7 * plane_elems + p] : 0.0f;
-        rc[r] = in[r] ? rcp[p] : 0.0f;
-        ix[r] = in[r] ? iwxp[p] : 0.0f;
-        iy[r] = in[r] ? iwyp[p] : 0.0f;
-        gr[r] = grad_sq(ix[r], iy[r]);                          // src/global_faldoi.cpp:648-652
-        rgr[r] = recip_f64(gr[r]);
+        s.u1[r] = in[r] ? src[0 * plane_elems + p] : 0.0f;
+        s.u2[r] = in[r] ? src[1 * plane_elems + p] : 0.0f;
+        s.x11[r] = in[r] ? src[4 * plane_elems + p] : 0.0f;
+        s.x12[r] = in[r] ? src[5 * plane_elems + p] : 0.0f;
+        s.x21[r] = in[r] ? src[6 * plane_elems + p] : 0.0f;
+        s.x22[r] = in[r] ? src[7 * plane_elems + p] : 0.0f;
+        s.rc[r] = in[r] ? rcp[p] : 0.0f;
+        s.ix[r] = in[r] ? iwxp[p] : 0.0f;
+        s.iy[r] = in[r] ? iwyp[p] : 0.0f;
+        s.gr[r] = grad_sq(s.ix[r], s.iy[r]);                    // src/global_faldoi.cpp:648-652
+        s.rgr[r] = recip_f64(s.gr[r]);
     }
     const bool ends_warp = (first & 2) != 0;                    // the launch surely ends its warp: ubar is dead afterwards
     first &= 1;
     if (first) {                                                // start of a warp: ubar = u (:659-660)
 #pragma unroll
-        for (int r = 0; r < R; ++r) { ub1[r] = u1[r]; ub2[r] = u2[r]; }
+        for (int r = 0; r < R; ++r) { s.ub1[r] = s.u1[r]; s.ub2[r] = s.u2[r]; }
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int p = in[r] ? (gy0 + r) * nx + gx : 0;
-            ub1[r] = in[r] ? src[2 * plane_elems + p] : 0.0f;
-            ub2[r] = in[r] ? src[3 * plane_elems + p] : 0.0f;
+            s.ub1[r] = in[r] ? src[2 * plane_elems + p] : 0.0f;
+            s.ub2[r] = in[r] ? src[3 * plane_elems + p] : 0.0f;
         }
     }
 
     // measurement aid (FALDOI_STAMPS=1, never in a timed run): when do the loads land, the iterations end, the stores drain
     if (stamps && threadIdx.x == 0) {
-        float sink = u1[R - 1] + x22[R - 1] + rc[R - 1] + iy[R - 1];
+        float sink = s.u1[R - 1] + s.x22[R - 1] + s.rc[R - 1] + s.iy[R - 1];
         asm volatile("" : "+v"(sink));                                // all loads of this wave have landed
         stamps[4 * t + 1] = __builtin_amdgcn_s_memrealtime();
     }
     for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;
-    s_ub1[wv][lane] = ub1[0];
-    s_ub2[wv][lane] = ub2[0];
+    s_ub1[wv][lane] = s.ub1[0];
+    s_ub2[wv][lane] = s.ub2[0];
 
-    // BORDER bit 0: the tile footprint contains image column 0 or nx-1; bit 1: row 0 or ny-1.  A tile on the left or right
-    // edge only (most border tiles) keeps the row formulas of the interior, and vice versa.
-    constexpr bool COLB = (BORDER & 1) != 0, ROWB = (BORDER & 2) != 0;
-    const bool last_c = COLB && (gx == nx - 1);
-    const bool first_c = COLB && (gx == 0);
-
-    for (int it = 0; it < iters; ++it) {
-        // Rows whose values can still reach the owned rows [halo, TH-halo) before the launch ends:
-        // after this iteration u is needed on tile rows [need_lo, need_hi), the new duals one row
-        // further up (the divergence reads xi12/xi22 of the row above).  Everything else is skipped
-        // (scalar tests: tile row = wv*R + r is wave-uniform).
-        const int reach = iters - 1 - it;
-        const int need_lo = halo - reach, need_hi = TH - halo + reach;
-        __syncthreads();                                       // ubar row 0 of every wave visible
-        // ---- dual step: forward gradient of ubar (:725-726) + ofTVl2_getD (:735) ----
-        if (wave_live && wv * R + R > need_lo - 1 && wv * R < need_hi) {
-            const float dn1 = (wv < NW - 1) ? s_ub1[wv < NW - 1 ? wv + 1 : wv][lane] : 0.0f;
-            const float dn2 = (wv < NW - 1) ? s_ub2[wv < NW - 1 ? wv + 1 : wv][lane] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (wv * R + r < need_lo - 1 || wv * R + r >= need_hi) continue;
-                // neighbours are fetched inside the executed block so the DPP moves fold into the
-                // subtractions (v_sub_f32_dpp)
-                const float r1 = lane_right(ub1[r]);
-                const float r2 = lane_right(ub2[r]);
-                const float d1 = (r < R - 1) ? ub1[r < R - 1 ? r + 1 : r] : dn1;
-                const float d2 = (r < R - 1) ? ub2[r < R - 1 ? r + 1 : r] : dn2;
-                const bool last_r = ROWB && (gy0 + r == ny - 1);
-                dual_step(x11[r], x12[r], x21[r], x22[r],
-                          fwd_diff(r1, ub1[r], last_c), fwd_diff(d1, ub1[r], last_r),
-                          fwd_diff(r2, ub2[r], last_c), fwd_diff(d2, ub2[r], last_r), prm.tau);
-            }
-            s_x12[wv][lane] = x12[R - 1];
-            s_x22[wv][lane] = x22[R - 1];
-        }
-        __syncthreads();                                       // new duals' last rows visible
-        // ---- primal step: divergence (:745-746), TH (:690-718), getP (:770), relax (:780) ----
-        if (wave_live && wv * R + R > need_lo && wv * R < need_hi) {
-            const float up12 = (wv > 0) ? s_x12[wv > 0 ? wv - 1 : 0][lane] : 0.0f;
-            const float up22 = (wv > 0) ? s_x22[wv > 0 ? wv - 1 : 0][lane] : 0.0f;
-            float emax = 0.0f;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int gy = gy0 + r;
-                if (wv * R + r < need_lo || wv * R + r >= need_hi) continue;
-                const float l11 = lane_left(x11[r]);
-                const float l21 = lane_left(x21[r]);
-                const float t12 = (r > 0) ? x12[r > 0 ? r - 1 : 0] : up12;
-                const float t22 = (r > 0) ? x22[r > 0 ? r - 1 : 0] : up22;
-                float div1, div2;
-                if (BORDER) {
-                    const PixClass pc{ first_c, last_c, ROWB && gy == 0, ROWB && gy == ny - 1 };
-                    div1 = div_sample(x11[r], l11, x12[r], t12, pc);
-                    div2 = div_sample(x21[r], l21, x22[r], t22, pc);
-                } else {                                       // src/utils.cpp:250-256
-                    div1 = (x11[r] - l11) + (x12[r] - t12);
-                    div2 = (x21[r] - l21) + (x22[r] - t22);
-                }
-                float v1, v2;
-                threshold_step(rc[r], ix[r], iy[r], gr[r], rgr[r], u1[r], u2[r], prm.l_t, v1, v2);
-                const float e = primal_step(u1[r], u2[r], ub1[r], ub2[r], v1, v2, div1, div2, prm.theta,
-                                            prm.rtheta, prm.tau);
-                emax = (own[r] && e > emax) ? e : emax;
-            }
-            s_ub1[wv][lane] = ub1[0];
-            s_ub2[wv][lane] = ub2[0];
-            // per-lane running maximum of this iteration (values >= 0: uint order == float order;
-            // max is order-independent => deterministic); reduced across lanes once, at the end
-            atomicMax(&s_err[it][lane], __float_as_uint(emax));
-        }
-    }
+    tvl1_iterate<R, NW, BORDER>(s, iters, track_from, halo, gx, gy0, nx, ny, lane, wv, wave_live, prm, s_ub1, s_ub2, s_x12, s_x22,
+                                s_err);
 
     if (stamps && threadIdx.x == 0) stamps[4 * t + 2] = __builtin_amdgcn_s_memrealtime();
     // ---- store the owned interior into the other state buffer ----
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        if (own[r]) {
+        if (s.own[r]) {
             const int p = (gy0 + r) * nx + gx;
-            dst[0 * plane_elems + p] = u1[r];
-            dst[1 * plane_elems + p] = u2[r];
+            dst[0 * plane_elems + p] = s.u1[r];
+            dst[1 * plane_elems + p] = s.u2[r];
             if (!ends_warp) {                                   // the next warp starts from ubar = u (:659-660)
-                dst[2 * plane_elems + p] = ub1[r];
-                dst[3 * plane_elems + p] = ub2[r];
+                dst[2 * plane_elems + p] = s.ub1[r];
+                dst[3 * plane_elems + p] = s.ub2[r];
             }
-            dst[4 * plane_elems + p] = x11[r];
-            dst[5 * plane_elems + p] = x12[r];
-            dst[6 * plane_elems + p] = x21[r];
-            dst[7 * plane_elems + p] = x22[r];
+            dst[4 * plane_elems + p] = s.x11[r];
+            dst[5 * plane_elems + p] = s.x12[r];
+            dst[6 * plane_elems + p] = s.x21[r];
+            dst[7 * plane_elems + p] = s.x22[r];
         }
     }
     __syncthreads();
@@ -455,19 +513,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamps[4 * t + 3] = __builtin_amdgcn_s_memrealtime();
     }
-    // wave i reduces iteration i's 64 per-lane maxima
-    for (int i = wv; i < kMaxChunk; i += NW) {
-        float m = (i < iters) ? __uint_as_float(s_err[i][lane]) : 0.0f;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float other = __shfl_xor(m, o);
-            m = other > m ? other : m;
-        }
-        if (lane == 0) {
-            const size_t slot = (size_t)err_slot * ntiles * npairs + t;
-            err_out[slot * kMaxChunk + i] = m;
-        }
-    }
+    tvl1_store_errors<NW>(s_err, iters, lane, wv, err_out + ((size_t)err_slot * ntiles * npairs + t) * kMaxChunk);
 }
 
 template <int R, int NW>
@@ -492,9 +538,11 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     const int tile = t - pair * ntiles;
     const int tyi = tile / ntx, txi = tile - tyi * ntx;
 
-    int cur, first, iters;
+    int cur, first, iters, track_from = 0;
     if (static_mode) {
         cur = s_cur; first = s_first; iters = s_iters;
+        // a static schedule reports the last iteration of each warp only (tvl1_static_stats_kernel)
+        track_from = (s_first & 2) ? s_iters - 1 : s_iters;
     } else {
         const PairCtl c = ctl[pair];
         cur = c.cur; iters = c.iters;
@@ -508,7 +556,7 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     const bool colb = X0 <= 0 || X0 + kTileW >= nx, rowb = Y0 <= 0 || Y0 + TH >= ny;
 #define FALDOI_BODY(B)                                                                                                  \
     tvl1_chunk_body<R, NW, B>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out, cur,   \
-                              first, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err, stamps)
+                              first, iters, track_from, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err, stamps)
     if (colb && rowb) FALDOI_BODY(3);
     else if (colb) FALDOI_BODY(1);
     else if (rowb) FALDOI_BODY(2);

@@ -1,0 +1,341 @@
+// tvl1_persist_kernel.hpp -- the whole static TV-L1 schedule of ONE pair in ONE launch (gfx950 / MI355X).
+//
+// The per-launch kernel of tvl1_kernels.hpp pays ~8 us per launch besides its iterations (launch gap, loading and storing the
+// whole tile state, the end-of-kernel write-back) plus one pointwise launch per outer warp; at 1024x436 with 10 iterations per
+// warp (BASELINE configs[1]) that is a quarter of the solve.  When the pair's tiles fit the chip one-per-CU, this kernel keeps
+// every tile's state in registers for the whole solve (all `warps` x `max_inner` iterations) and only exchanges the halo:
+//
+//   per outer warp     bicubic warp of the owned pixels (rho_c, I1wx, I1wy stay in registers)
+//   per chunk of k     publish the owned pixels near the tile edge (write-through 16-B stores into the tile's exchange slab,
+//   iterations         double buffered), raise the tile's epoch flag; wait for the (up to) eight neighbours' flags; fetch the
+//                      halo from their slabs; k iterations (tvl1_iterate, the same code as the per-launch kernel)
+//
+// No grid-wide barrier: a tile only waits for its neighbours.  The arithmetic and its order per pixel are those of the
+// per-launch path, and every halo value is the owner's value, so the results are bit-identical to it (tested).
+//
+// Inter-workgroup visibility (per-CU L1 and per-XCD L2 are not coherent): every handed-off byte is stored with sc1 (write-
+// through), each storing wave drains (s_waitcnt vmcnt(0)) before the workgroup's barrier, one lane then stores the flag with
+// an agent-scope atomic store; the consumer polls the flags with agent-scope atomic loads (one wave), a workgroup barrier, then
+// loads the bytes with sc1 loads only (bypass L1; the lines are not in this XCD's L2 before the first load after the
+// store, because sc1 stores drop them).  No handed-off byte is ever read by a plain load inside the launch.
+//
+// Residency: one workgroup per tile, tiles <= CUs (host-checked), plain launch.  Every spin is bounded: after `spin_limit`
+// polls a workgroup raises the abort word and returns; every poller also watches the abort word, so the grid drains and the
+// host reports FALDOI_ERR_HIP instead of hanging.
+#pragma once
+#include "tvl1_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace faldoi {
+
+constexpr int kXPlanes = 11;       // exchange slots: u1 u2 ub1 ub2 xi11 xi12 xi21 xi22 rho_c I1wx I1wy
+constexpr int kFlagStride = 32;    // unsigned words between two tiles' flags: one 128-B line each
+constexpr int kPersistStamps = 16;  // stamps per tile (measurement aid)
+
+typedef unsigned int xvec4 __attribute__((ext_vector_type(4)));
+
+struct PersistArgs {
+    float *base;                   // the pair's slab (planes of tvl1_kernels.hpp)
+    size_t plane_elems;
+    int nx, ny, ntx, nty;
+    int hx, hy;                    // halo columns (= iterations per chunk) and halo rows (multiple of R, >= hx)
+    TvConst prm;                   // prm.chunk = iterations per exchange
+    float *err_out;                // [warps][ntiles][kMaxChunk]
+    float *xslab;                  // [2][ntiles][kXPlanes][NW][64] x 16 B
+    unsigned xslab_bytes;
+    unsigned *flags;               // [ntiles] epoch flags, kFlagStride words apart; then the abort word
+    unsigned spin_limit;
+    unsigned long long *stamps;    // optional: [ntiles][kPersistStamps], taken during warp `stamp_warp`
+    int stamp_warp;
+};
+
+template <int R>
+__device__ __forceinline__ xvec4 pack_rows(const float (&v)[R])
+{
+    xvec4 o = { 0u, 0u, 0u, 0u };
+    o.x = __float_as_uint(v[0]);
+    if (R > 1) o.y = __float_as_uint(v[R > 1 ? 1 : 0]);
+    if (R > 2) o.z = __float_as_uint(v[R > 2 ? 2 : 0]);
+    if (R > 3) o.w = __float_as_uint(v[R > 3 ? 3 : 0]);
+    return o;
+}
+template <int R>
+__device__ __forceinline__ void unpack_rows(float (&v)[R], const xvec4 o, bool take)
+{
+    v[0] = take ? __uint_as_float(o.x) : v[0];
+    if (R > 1) v[R > 1 ? 1 : 0] = take ? __uint_as_float(o.y) : v[R > 1 ? 1 : 0];
+    if (R > 2) v[R > 2 ? 2 : 0] = take ? __uint_as_float(o.z) : v[R > 2 ? 2 : 0];
+    if (R > 3) v[R > 3 ? 3 : 0] = take ? __uint_as_float(o.w) : v[R > 3 ? 3 : 0];
+}
+
+template <int R, int NW, int BORDER>
+__device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, int txi, int tyi,
+                                                  float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
+                                                  float (*s_x22)[kTileW], unsigned (*s_err)[kTileW], int *s_ctl)
+{
+    static_assert(R >= 2 && R <= 4, "a thread's rows travel as one 16-byte vector");
+    constexpr int TH = R * NW;
+    const int nx = a.nx, ny = a.ny, ntx = a.ntx, nty = a.nty;
+    const int ntiles = ntx * nty;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Sx = kTileW - 2 * a.hx, Sy = TH - 2 * a.hy;
+    const int gx = txi * Sx - a.hx + lane;
+    const int gy0 = tyi * Sy - a.hy + wv * R;           // scalar; a multiple of R (hy and Sy are): a thread's rows share their owner
+    const bool col_in = gx >= 0 && gx < nx;
+    const bool col_own = col_in && gx >= txi * Sx && gx < (txi + 1) * Sx;
+    const bool group_in = gy0 >= 0 && gy0 < ny;
+    const bool group_own = group_in && gy0 >= tyi * Sy && gy0 < (tyi + 1) * Sy;
+    const bool wave_live = group_in;
+    const bool owner = col_own && group_own;
+    const bool halo = col_in && group_in && !owner;
+    // owned pixels a neighbour's footprint covers
+    const bool ring = owner && (gx - txi * Sx < a.hx || (txi + 1) * Sx - 1 - gx < a.hx || gy0 - tyi * Sy < a.hy ||
+                                (tyi + 1) * Sy - (gy0 + R) < a.hy);
+
+    // exchange slab addressing, in bytes (host: the whole slab is below 4 GB)
+    const unsigned plane_stride = (unsigned)(NW * kTileW) * 16u;
+    const unsigned tile_stride = plane_stride * (unsigned)kXPlanes;
+    const unsigned parity_stride = tile_stride * (unsigned)ntiles;
+    const unsigned pub_off = (unsigned)t * tile_stride + (unsigned)(wv * kTileW + lane) * 16u;
+    unsigned src_off = 0;
+    if (halo) {
+        const int txp = gx / Sx, typ = gy0 / Sy;
+        const int lane_p = gx - txp * Sx + a.hx, wave_p = (gy0 - typ * Sy + a.hy) / R;
+        src_off = (unsigned)(typ * ntx + txp) * tile_stride + (unsigned)(wave_p * kTileW + lane_p) * 16u;
+    }
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xslab, 0, a.xslab_bytes, 0x00020000);
+    unsigned *abort_word = a.flags + (size_t)ntiles * kFlagStride;
+
+    float *slab = a.base;
+    const float *ini = slab + (size_t)P_STATE0 * a.plane_elems;
+    float *dst = slab + (size_t)P_STATE1 * a.plane_elems;
+    const float *I0 = slab + (size_t)P_I0 * a.plane_elems;
+    const float *I1 = slab + (size_t)P_I1 * a.plane_elems;
+    const float *I1x = slab + (size_t)P_I1X * a.plane_elems;
+    const float *I1y = slab + (size_t)P_I1Y * a.plane_elems;
+
+    TileState<R> s;
+    bool in[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = gy0 + r;
+        in[r] = col_in && gy >= 0 && gy < ny;
+        s.own[r] = in[r] && owner;
+        const int p = s.own[r] ? gy * nx + gx : 0;
+        s.u1[r] = s.own[r] ? ini[0 * a.plane_elems + p] : 0.0f;
+        s.u2[r] = s.own[r] ? ini[1 * a.plane_elems + p] : 0.0f;
+        s.x11[r] = s.own[r] ? ini[4 * a.plane_elems + p] : 0.0f;
+        s.x12[r] = s.own[r] ? ini[5 * a.plane_elems + p] : 0.0f;
+        s.x21[r] = s.own[r] ? ini[6 * a.plane_elems + p] : 0.0f;
+        s.x22[r] = s.own[r] ? ini[7 * a.plane_elems + p] : 0.0f;
+        s.ub1[r] = s.ub2[r] = 0.0f;
+        s.rc[r] = s.ix[r] = s.iy[r] = s.gr[r] = 0.0f;
+        s.rgr[r] = 0.0;
+    }
+    for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;
+
+    unsigned epoch = 0;
+    for (int w = 0; w < a.prm.warps; ++w) {
+        const bool stamp = a.stamps && w == a.stamp_warp && threadIdx.x == 0;
+        unsigned long long *st = a.stamps + (size_t)t * kPersistStamps;
+        if (stamp) st[0] = __builtin_amdgcn_s_memrealtime();
+        // ---- the warp constants of the owned pixels (src/global_faldoi.cpp:635-657; tvl1_warp_kernel) ----
+        // (dealing the owned pixels to all threads through LDS, two pixels each instead of R for the owners and none for the
+        // halo, was measured: no faster -- the phase is bound by its ~530 vector instructions per pixel, not by their spread)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float rc = 0.0f, wx = 0.0f, wy = 0.0f;               // the halo's constants arrive with the exchange
+            if (!(kWhatIf & 32) && s.own[r]) {
+                const int gy = gy0 + r;
+                float i0v = I0[gy * nx + gx];
+                asm volatile("" : "+v"(i0v));
+                const float uu = (float)gx + s.u1[r];            // src/bicubic_interpolation.c:259-260
+                const float vv = (float)gy + s.u2[r];
+                const BicubicTaps tp = bicubic_taps(uu, vv, nx, ny);
+                float w0 = 0.0f;                                 // border_out = true (:635-637)
+                if (!tp.clamped) {
+                    w0 = bicubic_eval_rows(I1, tp, nx);
+                    wx = bicubic_eval_rows(I1x, tp, nx);
+                    wy = bicubic_eval_rows(I1y, tp, nx);
+                }
+                rc = rho_const(w0, wx, wy, s.u1[r], s.u2[r], i0v);
+            }
+            s.rc[r] = rc;
+            s.ix[r] = wx;
+            s.iy[r] = wy;
+        }
+        if (stamp) {
+            float sink = s.rc[0] + s.rc[R - 1] + s.iy[R - 1];
+            asm volatile("" : "+v"(sink));
+            st[1] = __builtin_amdgcn_s_memrealtime();
+        }
+
+        for (int n = 0; n < a.prm.max_inner;) {
+            const int left = a.prm.max_inner - n;
+            const int it = left < a.prm.chunk ? left : a.prm.chunk;
+            const bool first = n == 0;
+            ++epoch;
+            const unsigned par = (epoch & 1u) * parity_stride;
+
+            // ---- publish: write-through, one 16-byte vector (the thread's R rows) per plane ----
+            if (ring) {
+                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u1), rsrc, par + pub_off + 0u * plane_stride, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u2), rsrc, par + pub_off + 1u * plane_stride, 0, 16);
+                if (!first) {                                     // at the start of a warp ubar = u (:659-660)
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub1), rsrc, par + pub_off + 2u * plane_stride, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub2), rsrc, par + pub_off + 3u * plane_stride, 0, 16);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x11), rsrc, par + pub_off + 4u * plane_stride, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x12), rsrc, par + pub_off + 5u * plane_stride, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x21), rsrc, par + pub_off + 6u * plane_stride, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x22), rsrc, par + pub_off + 7u * plane_stride, 0, 16);
+                if (first) {
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.rc), rsrc, par + pub_off + 8u * plane_stride, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ix), rsrc, par + pub_off + 9u * plane_stride, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.iy), rsrc, par + pub_off + 10u * plane_stride, 0, 16);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the barrier
+            if (a.stamps && w == a.stamp_warp && threadIdx.x == 64 * (NW / 2)) st[first ? 7 : 12] = __builtin_amdgcn_s_memrealtime();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(a.flags + (size_t)t * kFlagStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (stamp) st[first ? 2 : 8] = __builtin_amdgcn_s_memrealtime();
+            }
+
+            // ---- wait for the neighbours' epoch (one wave: lanes 0..7 one neighbour each, lane 8 the abort word) ----
+            if (wv == 0) {
+                const int d = lane < 4 ? lane : lane + 1;         // 0..8 without the centre
+                const int ax = txi + d % 3 - 1, ay = tyi + d / 3 - 1;
+                const bool has = lane < 8 && ax >= 0 && ax < ntx && ay >= 0 && ay < nty;
+                const unsigned *pw = (lane == 8) ? abort_word : a.flags + (size_t)(has ? ay * ntx + ax : t) * kFlagStride;
+                bool failed = false;
+                for (unsigned spins = 0;; ++spins) {
+                    unsigned v = 0;
+                    if (lane < 9) v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool behind = !(kWhatIf & 16) && has && (int)(v - epoch) < 0;
+                    const bool aborted = lane == 8 && v != 0u;
+                    if (__builtin_amdgcn_ballot_w64(aborted) != 0ull) { failed = true; break; }
+                    if (__builtin_amdgcn_ballot_w64(behind) == 0ull) break;
+                    if (spins >= a.spin_limit) {
+                        if (lane == 0) __hip_atomic_store(abort_word, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        failed = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (lane == 0) s_ctl[0] = failed ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_ctl[0]) return;                                 // uniform: the whole workgroup leaves
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the loads below the poll
+            if (stamp) st[first ? 3 : 9] = __builtin_amdgcn_s_memrealtime();
+
+            // ---- fetch the halo from its owners' slabs (sc1 loads only) ----
+            {
+                xvec4 q[kXPlanes];
+#pragma unroll
+                for (int k = 0; k < kXPlanes; ++k) q[k] = xvec4{ 0u, 0u, 0u, 0u };
+                if (halo) {
+                    q[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 0u * plane_stride, 0, 16);
+                    q[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 1u * plane_stride, 0, 16);
+                    if (!first) {
+                        q[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 2u * plane_stride, 0, 16);
+                        q[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 3u * plane_stride, 0, 16);
+                    }
+                    q[4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 4u * plane_stride, 0, 16);
+                    q[5] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 5u * plane_stride, 0, 16);
+                    q[6] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 6u * plane_stride, 0, 16);
+                    q[7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 7u * plane_stride, 0, 16);
+                    if (first) {
+                        q[8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 8u * plane_stride, 0, 16);
+                        q[9] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 9u * plane_stride, 0, 16);
+                        q[10] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 10u * plane_stride, 0, 16);
+                    }
+                }
+                unpack_rows<R>(s.u1, q[0], halo);
+                unpack_rows<R>(s.u2, q[1], halo);
+                unpack_rows<R>(s.ub1, q[2], halo && !first);
+                unpack_rows<R>(s.ub2, q[3], halo && !first);
+                unpack_rows<R>(s.x11, q[4], halo);
+                unpack_rows<R>(s.x12, q[5], halo);
+                unpack_rows<R>(s.x21, q[6], halo);
+                unpack_rows<R>(s.x22, q[7], halo);
+                unpack_rows<R>(s.rc, q[8], halo && first);
+                unpack_rows<R>(s.ix, q[9], halo && first);
+                unpack_rows<R>(s.iy, q[10], halo && first);
+            }
+            if (first) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    s.ub1[r] = s.u1[r];                            // start of a warp: ubar = u (:659-660)
+                    s.ub2[r] = s.u2[r];
+                    s.gr[r] = grad_sq(s.ix[r], s.iy[r]);           // :648-652
+                    s.rgr[r] = recip_f64(s.gr[r]);
+                }
+            }
+            if (stamp) {
+                float sink = s.u1[0] + s.x22[R - 1] + s.iy[R - 1];
+                asm volatile("" : "+v"(sink));
+                st[first ? 4 : 10] = __builtin_amdgcn_s_memrealtime();
+            }
+            s_ub1[wv][lane] = s.ub1[0];
+            s_ub2[wv][lane] = s.ub2[0];
+
+            const bool ends_warp = n + it >= a.prm.max_inner;
+            tvl1_iterate<R, NW, BORDER>(s, it, ends_warp ? it - 1 : it, a.hy, gx, gy0, nx, ny, lane, wv, wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
+                                        s_err);
+            if (stamp) st[first ? 5 : 11] = __builtin_amdgcn_s_memrealtime();
+
+            __syncthreads();                                       // the last iteration's maxima are in s_err
+            if (ends_warp)                                         // the chunk that ends the warp: what the stats kernel reads
+                tvl1_store_errors<NW>(s_err, it, lane, wv, a.err_out + ((size_t)w * ntiles + t) * kMaxChunk);
+            for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;   // the same wave that read row i
+            n += it;
+        }
+        if (stamp) st[6] = __builtin_amdgcn_s_memrealtime();
+    }
+
+    // ---- the solved state of the owned pixels (ubar is dead after the last warp) ----
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (s.own[r]) {
+            const int p = (gy0 + r) * nx + gx;
+            dst[0 * a.plane_elems + p] = s.u1[r];
+            dst[1 * a.plane_elems + p] = s.u2[r];
+            dst[4 * a.plane_elems + p] = s.x11[r];
+            dst[5 * a.plane_elems + p] = s.x12[r];
+            dst[6 * a.plane_elems + p] = s.x21[r];
+            dst[7 * a.plane_elems + p] = s.x22[r];
+        }
+    }
+}
+
+template <int R, int NW>
+__global__ __launch_bounds__(64 * NW) void tvl1_persist_kernel(PersistArgs a)
+{
+    constexpr int TH = R * NW;
+    __shared__ float s_ub1[NW][kTileW];
+    __shared__ float s_ub2[NW][kTileW];
+    __shared__ float s_x12[NW][kTileW];
+    __shared__ float s_x22[NW][kTileW];
+    __shared__ unsigned s_err[kMaxChunk][kTileW];
+    __shared__ int s_ctl[4];
+
+    const int per = gridDim.x >> 3;                                // XCD-aware tile order, as tvl1_chunk_kernel
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= a.ntx * a.nty) return;
+    const int tyi = t / a.ntx, txi = t - tyi * a.ntx;
+    const int X0 = txi * (kTileW - 2 * a.hx) - a.hx, Y0 = tyi * (TH - 2 * a.hy) - a.hy;
+    const bool colb = X0 <= 0 || X0 + kTileW >= a.nx, rowb = Y0 <= 0 || Y0 + TH >= a.ny;
+#define FALDOI_BODY(B) tvl1_persist_body<R, NW, B>(a, t, txi, tyi, s_ub1, s_ub2, s_x12, s_x22, s_err, s_ctl)
+    if (colb && rowb) FALDOI_BODY(3);
+    else if (colb) FALDOI_BODY(1);
+    else if (rowb) FALDOI_BODY(2);
+    else FALDOI_BODY(0);
+#undef FALDOI_BODY
+}
+
+}  // namespace faldoi

@@ -121,13 +121,20 @@ int faldoi_tvl1_batch_download(faldoi_tvl1_batch *b, int pair, float *u, float *
  * solve_ms = the whole solve; chunk_launches / px_iters = launches of the fused iteration kernel
  * and pixel-iterations they advanced; chunk_kernel_ms = sum over those launches of the time
  * between an event pair placed around each one (measured only when the environment variable
- * FALDOI_EVENT_TIMING=1 is set and tol_stop == 0; otherwise 0).  Any pointer may be NULL. */
+ * FALDOI_EVENT_TIMING=1 is set and tol_stop == 0, and always for the one launch of the persistent kernel;
+ * otherwise 0).  Any pointer may be NULL. */
 int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *chunk_launches,
                                   long *px_iters, double *chunk_kernel_ms);
 
 /* Launch schedule the last batch_solve chose: tile = 64 columns x rows_per_thread*waves rows, `chunk` inner
  * iterations per launch of the fused kernel (reporting only; results do not depend on it). */
 int faldoi_tvl1_batch_last_schedule(faldoi_tvl1_batch *b, int *rows_per_thread, int *waves, int *chunk);
+/* *persistent = 1 when the last batch_solve ran as ONE launch of the persistent kernel (a static schedule, tol_stop == 0, of
+ * one pair whose tiles fit the chip one per compute unit: every tile's state stays in registers for the whole solve and only
+ * the halo is exchanged between workgroups); chunk_launches is then 1, `chunk` the iterations between two exchanges and
+ * chunk_kernel_ms that launch's duration.  The environment variable FALDOI_PERSIST=0 selects the per-launch path; results are
+ * identical on both. */
+int faldoi_tvl1_batch_last_persistent(faldoi_tvl1_batch *b, int *persistent);
 
 /* ---------------------------------------------------------------- primitives (host buffers)
  * Stand-alone launches of the device functions the fused kernel is made of, for stage-level

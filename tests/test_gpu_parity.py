@@ -140,6 +140,62 @@ def test_tvl1_fixed_schedule_bit_exact(ctx, oracle):
     _compare_solve(ctx, oracle, i0n, i1n, np.zeros_like(gt), warps=4, max_inner=23, tol_stop=0, chunk=10)
 
 
+def _static_solve(ctx, i0n, i1n, u0, xi0, **prm):
+    h, w = i0n.shape
+    b = F.Tvl1Batch(ctx, 1, w, h)
+    try:
+        b.upload(0, i0n, i1n, u0, xi0)
+        its, errs, _, launches = b.solve(tol_stop=0, **prm)
+        u, xi = b.download(0, want_xi=True)
+        return u, xi, its[0].copy(), errs[0].copy(), launches, b.last_persistent(), b.last_schedule()
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("w,h,warps,inner,cfg", [(192, 128, 3, 10, None), (300, 200, 4, 10, "3,16,5"), (300, 200, 3, 12, "4,13,5"),
+                                                 (257, 131, 2, 9, "4,11,4"), (640, 360, 3, 10, None), (1024, 436, 4, 10, None),
+                                                 (1024, 436, 2, 16, "4,16,8"), (64, 48, 2, 5, "3,14,3"), (70, 3, 2, 7, None),
+                                                 (2, 2, 2, 4, None)])
+def test_persistent_kernel_equals_per_launch_path_and_checker(ctx, oracle, monkeypatch, w, h, warps, inner, cfg):
+    # a static schedule of one pair runs as ONE launch that keeps every tile in registers and only exchanges halos between
+    # workgroups (tvl1_persist_kernel.hpp); FALDOI_PERSIST=0 is the launch-per-chunk path.  Same bits from both, and from the
+    # CPU checker, for several tile geometries (R,NW,k), image sizes with ragged last tiles, and a non-zero start.
+    i0n, i1n, gt = synthetic_pair(w, h, seed=w + h, amp=2.0)
+    rng = np.random.default_rng(w * h)
+    u0 = (0.5 * gt).astype(np.float32)
+    xi0 = (rng.standard_normal((4, h, w)) * 0.6).astype(np.float32)
+    ou, oit, oerr, oxi = oracle.tvl1_global(i0n, i1n, u0, xi=xi0, lam=40.0, theta=0.3, tau=0.125, tol=0.01, warps=warps,
+                                            max_inner=inner, tol_stop=False)
+    monkeypatch.setenv("FALDOI_PERSIST", "0")
+    ref = _static_solve(ctx, i0n, i1n, u0, xi0, warps=warps, max_inner=inner)
+    assert not ref[5]
+    monkeypatch.setenv("FALDOI_PERSIST", "1")
+    if cfg:
+        monkeypatch.setenv("FALDOI_PERSIST_CFG", cfg)
+    new = _static_solve(ctx, i0n, i1n, u0, xi0, warps=warps, max_inner=inner)
+    assert new[5] and new[4] == 1, "the persistent path was not taken"
+    for got in (ref, new):
+        assert bits_equal(got[0], ou), mismatch_report(got[0], ou)
+        assert bits_equal(got[1], oxi), mismatch_report(got[1], oxi)
+        assert list(got[2]) == list(oit) and bits_equal(got[3], oerr)
+
+
+def test_persistent_kernel_gives_up_cleanly_and_the_per_launch_path_takes_over(ctx, monkeypatch, capfd):
+    # every spin in the persistent kernel is bounded; with the bound set to one poll some tile gives up in the first exchange,
+    # raises the abort word, all workgroups leave, and the solve is redone on the per-launch path: same result, no hang
+    i0n, i1n, gt = synthetic_pair(640, 360, seed=3)
+    z = np.zeros_like(gt)
+    monkeypatch.setenv("FALDOI_PERSIST", "0")
+    ref = _static_solve(ctx, i0n, i1n, z, None, warps=3, max_inner=10)
+    monkeypatch.setenv("FALDOI_PERSIST", "1")
+    monkeypatch.setenv("FALDOI_PERSIST_SPINS", "1")
+    new = _static_solve(ctx, i0n, i1n, z, None, warps=3, max_inner=10)
+    assert bits_equal(ref[0], new[0]) and bits_equal(ref[1], new[1]) and bits_equal(ref[3], new[3])
+    if not new[5]:                                   # (all neighbours ready at the first poll is possible, just unlikely)
+        assert new[4] == ref[4]
+        assert "per-launch path" in capfd.readouterr().err
+
+
 def test_tvl1_nonzero_duals_and_parameters(ctx, oracle):
     i0n, i1n, gt = synthetic_pair(96, 80, seed=11)
     rng = np.random.default_rng(1)
