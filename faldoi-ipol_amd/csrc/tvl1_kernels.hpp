@@ -301,14 +301,11 @@ struct TileState {
 // below and by the persistent kernel (tvl1_persist_kernel.hpp).  halo_y = rows of halo above and below the owned rows; the
 // caller has put row 0 of every wave's ubar into s_ub1 / s_ub2 and zeroed s_err[0..iters).  Per-lane maxima of |du|^2 over
 // the owned pixels are left in s_err[it][lane].
-//
-// track_from: iterations it >= track_from record max |du|^2; the others skip it (a static schedule only ever reads the
-// last iteration of a warp; the primal step is compiled twice, with and without the bookkeeping).
-template <int R, int NW, int BORDER, bool TRACK>
-__device__ __forceinline__ void tvl1_one_iteration(TileState<R> &s, int it, int iters, int halo_y, int gx, int gy0, int nx,
-                                                   int ny, int lane, int wv, bool wave_live, const TvConst &prm,
-                                                   float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
-                                                   float (*s_x22)[kTileW], unsigned (*s_err)[kTileW])
+template <int R, int NW, int BORDER>
+__device__ __forceinline__ void tvl1_iterate(TileState<R> &s, int iters, int halo_y, int gx, int gy0, int nx, int ny,
+                                             int lane, int wv, bool wave_live, const TvConst &prm,
+                                             float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
+                                             float (*s_x22)[kTileW], unsigned (*s_err)[kTileW])
 {
     constexpr int TH = R * NW;
     // BORDER bit 0: the tile footprint contains image column 0 or nx-1; bit 1: row 0 or ny-1.  A tile on the left or right
@@ -317,7 +314,9 @@ __device__ __forceinline__ void tvl1_one_iteration(TileState<R> &s, int it, int 
     const bool last_c = COLB && (gx == nx - 1);
     const bool first_c = COLB && (gx == 0);
 
-    {
+    // (recording max |du|^2 only in the iterations a static schedule reports, with the loop body compiled twice, was measured:
+    // 2.4 % SLOWER than recording it always -- the doubled body costs more than the eight instructions per pixel it saves)
+    for (int it = 0; it < iters; ++it) {
         // Rows whose values can still reach the owned rows [halo_y, TH-halo_y) before the launch ends:
         // after this iteration u is needed on tile rows [need_lo, need_hi), the new duals one row
         // further up (the divergence reads xi12/xi22 of the row above).  Everything else is skipped
@@ -373,30 +372,14 @@ __device__ __forceinline__ void tvl1_one_iteration(TileState<R> &s, int it, int 
                 threshold_step(s.rc[r], s.ix[r], s.iy[r], s.gr[r], s.rgr[r], s.u1[r], s.u2[r], prm.l_t, v1, v2);
                 const float e = primal_step(s.u1[r], s.u2[r], s.ub1[r], s.ub2[r], v1, v2, div1, div2, prm.theta,
                                             prm.rtheta, prm.tau);
-                if (TRACK) emax = (s.own[r] && e > emax) ? e : emax;
+                emax = (s.own[r] && e > emax) ? e : emax;
             }
             s_ub1[wv][lane] = s.ub1[0];
             s_ub2[wv][lane] = s.ub2[0];
             // per-lane running maximum of this iteration (values >= 0: uint order == float order;
             // max is order-independent => deterministic); reduced across lanes once, at the end
-            if (TRACK) atomicMax(&s_err[it][lane], __float_as_uint(emax));
+            atomicMax(&s_err[it][lane], __float_as_uint(emax));
         }
-    }
-}
-
-template <int R, int NW, int BORDER>
-__device__ __forceinline__ void tvl1_iterate(TileState<R> &s, int iters, int track_from, int halo_y, int gx, int gy0, int nx,
-                                             int ny, int lane, int wv, bool wave_live, const TvConst &prm,
-                                             float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
-                                             float (*s_x22)[kTileW], unsigned (*s_err)[kTileW])
-{
-    for (int it = 0; it < iters; ++it) {
-        if (it >= track_from)
-            tvl1_one_iteration<R, NW, BORDER, true>(s, it, iters, halo_y, gx, gy0, nx, ny, lane, wv, wave_live, prm, s_ub1, s_ub2,
-                                                    s_x12, s_x22, s_err);
-        else
-            tvl1_one_iteration<R, NW, BORDER, false>(s, it, iters, halo_y, gx, gy0, nx, ny, lane, wv, wave_live, prm, s_ub1, s_ub2,
-                                                     s_x12, s_x22, s_err);
     }
 }
 
@@ -420,7 +403,7 @@ template <int R, int NW, int BORDER>
 __device__ __forceinline__ void tvl1_chunk_body(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int npairs, int ntiles, int t,
     int pair, int txi, int tyi, int halo, const TvConst &prm, float *__restrict__ err_out,
-    int cur, int first /* bit 0: starts a warp, bit 1: ends one */, int iters, int track_from, int err_slot,
+    int cur, int first /* bit 0: starts a warp, bit 1: ends one */, int iters, int err_slot,
     float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW], float (*s_x22)[kTileW],
     unsigned (*s_err)[kTileW], unsigned long long *stamps)
 {
@@ -487,8 +470,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
     s_ub1[wv][lane] = s.ub1[0];
     s_ub2[wv][lane] = s.ub2[0];
 
-    tvl1_iterate<R, NW, BORDER>(s, iters, track_from, halo, gx, gy0, nx, ny, lane, wv, wave_live, prm, s_ub1, s_ub2, s_x12, s_x22,
-                                s_err);
+    tvl1_iterate<R, NW, BORDER>(s, iters, halo, gx, gy0, nx, ny, lane, wv, wave_live, prm, s_ub1, s_ub2, s_x12, s_x22, s_err);
 
     if (stamps && threadIdx.x == 0) stamps[4 * t + 2] = __builtin_amdgcn_s_memrealtime();
     // ---- store the owned interior into the other state buffer ----
@@ -538,11 +520,9 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     const int tile = t - pair * ntiles;
     const int tyi = tile / ntx, txi = tile - tyi * ntx;
 
-    int cur, first, iters, track_from = 0;
+    int cur, first, iters;
     if (static_mode) {
         cur = s_cur; first = s_first; iters = s_iters;
-        // a static schedule reports the last iteration of each warp only (tvl1_static_stats_kernel)
-        track_from = (s_first & 2) ? s_iters - 1 : s_iters;
     } else {
         const PairCtl c = ctl[pair];
         cur = c.cur; iters = c.iters;
@@ -556,7 +536,7 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     const bool colb = X0 <= 0 || X0 + kTileW >= nx, rowb = Y0 <= 0 || Y0 + TH >= ny;
 #define FALDOI_BODY(B)                                                                                                  \
     tvl1_chunk_body<R, NW, B>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out, cur,   \
-                              first, iters, track_from, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err, stamps)
+                              first, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err, stamps)
     if (colb && rowb) FALDOI_BODY(3);
     else if (colb) FALDOI_BODY(1);
     else if (rowb) FALDOI_BODY(2);

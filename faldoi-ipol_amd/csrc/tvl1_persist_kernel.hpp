@@ -285,7 +285,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             s_ub2[wv][lane] = s.ub2[0];
 
             const bool ends_warp = n + it >= a.prm.max_inner;
-            tvl1_iterate<R, NW, BORDER>(s, it, ends_warp ? it - 1 : it, a.hy, gx, gy0, nx, ny, lane, wv, wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
+            tvl1_iterate<R, NW, BORDER>(s, it, a.hy, gx, gy0, nx, ny, lane, wv, wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
                                         s_err);
             if (stamp) st[first ? 5 : 11] = __builtin_amdgcn_s_memrealtime();
 

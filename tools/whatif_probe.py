@@ -14,6 +14,8 @@ OUT = os.path.join(ROOT, "tools", "_whatif")
 VARIANTS = {0: "product", 1: "no barriers in the iterations", 2: "duals never take the quotient path",
             4: "threshold quotient -> product", 8: "theta quotients -> products", 14: "no exact quotient at all",
             16: "no waiting for neighbours", 32: "no warp constants", 63: "all of the above"}
+if os.environ.get("FALDOI_WHATIF_ONLY"):
+    VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["FALDOI_WHATIF_ONLY"].split(",")}
 
 
 def build():
