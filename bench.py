@@ -189,14 +189,15 @@ def main():
     dt_max, px_iters = F.shard.reduce_timing(dt, px_iters_local, dist if use_dist else None, dev)
     per_rank = F.shard.gather_scalars(px_iters_local / dt / 1e6, dist if use_dist else None, dev)
 
-    # Durations of the two kernels of a step (outside the timed region), from whole-solve HIP-event times on the
-    # library's own stream.  Both kernels can be launched twice in a row without changing a bit: the per-warp kernel only
-    # writes the warp constants (FALDOI_WARP_REPEAT=2), the fused iteration kernel reads one state buffer and writes the
-    # other (FALDOI_CHUNK_REPEAT=2).  The difference of two whole-solve times is then the marginal cost of ONE more launch of
-    # that kernel in the real stream: its duration plus the gap to the next launch.  (No event sits between kernels: an
-    # event pair around every launch inflated the kernel by ~7 % in round 1.  rocprofv3's kernel-trace durations,
-    # profiles/r02_counters.json, exclude the gap but carry ~1 us of tracing overhead on kernels this short.)
-    kern = None
+    # Kernel durations, outside the timed region, from HIP events on the library's own stream.
+    #  * A static one-pair schedule runs as ONE launch of the persistent kernel (tvl1_persist_kernel.hpp); the library
+    #    brackets that launch with an event pair (one pair per solve: no measurable cost) -> pers["kernel_ms"].
+    #  * The launch-per-chunk path (FALDOI_PERSIST=0; batches, tolerance stop) has two kernels per warp.  Both can be launched
+    #    twice in a row without changing a bit: the per-warp kernel only writes the warp constants (FALDOI_WARP_REPEAT=2), the
+    #    fused iteration kernel reads one state buffer and writes the other (FALDOI_CHUNK_REPEAT=2).  The difference of two
+    #    whole-solve times is the marginal cost of ONE more launch of that kernel in the real stream: duration + launch gap.
+    #    (No event sits between kernels: an event pair around every launch inflated the kernel by ~7 % in round 1.)
+    kern = pers = None
     if rank == 0:
         reps = max(3, min(args.steps, 10))
 
@@ -207,6 +208,14 @@ def main():
             for k_ in env:
                 os.environ[k_] = "1"
             return t
+        if batch.last_persistent():
+            runs = []
+            for _ in range(reps):
+                ms = step()[2]
+                runs.append((batch.last_timing()[3], ms))
+            pers = dict(kernel_ms=min(r[0] for r in runs), solve_ms=min(r[1] for r in runs), schedule=batch.last_schedule())
+        had = os.environ.get("FALDOI_PERSIST")
+        os.environ["FALDOI_PERSIST"] = "0"
         t1 = best({})
         t2w = best({"FALDOI_WARP_REPEAT": "2"})
         t2c = best({"FALDOI_CHUNK_REPEAT": "2"})
@@ -215,11 +224,16 @@ def main():
         chunk_us = max(0.0, (t2c - t1) * 1e3 / nl1)
         kern = dict(chunk_us=chunk_us, warp_us=warp_us, solve_ms=t1, launches=nl1, schedule=batch.last_schedule(),
                     other_us_per_launch=(t1 * 1e3 - WARPS * warp_us - nl1 * chunk_us) / nl1)
+        if had is None:
+            del os.environ["FALDOI_PERSIST"]
+        else:
+            os.environ["FALDOI_PERSIST"] = had
+        step()                                            # the resident result is the headline path's again
 
     out = None
     if rank == 0:
         value = px_iters / dt_max / 1e6
-        out = headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, dev_ms, launches)
+        out = headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers, dev_ms, launches)
         sys.stderr.write("bench headline: %s\n" % json.dumps({k: out[k] for k in ("value", "unit", "n_gpus", "ms_per_step")}))
         sys.stderr.flush()
         if world == 1 and not args.no_cpu_baseline:
@@ -243,61 +257,96 @@ def guarded(out, name, fn):
         out.setdefault("secondary_errors", {})[name] = "%s: %s" % (type(e).__name__, e)
 
 
-def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, dev_ms, launches):
-    iters_per_launch = WARPS * INNER * args.steps / launches
+def _traffic(c):
+    """HBM bytes per launch from the two counter passes (gfx950: FETCH_SIZE reads half of a coalesced stream's bytes)."""
+    return int((2 * c["FETCH_SIZE_KB"] + c["WRITE_SIZE_KB"]) * 1024) if "FETCH_SIZE_KB" in c and "WRITE_SIZE_KB" in c else None
+
+
+def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers, dev_ms, launches):
     px = npairs * W * H
-    group_us = dev_ms * 1e3 / launches                     # whole solve / chunk launches (incl. the per-warp kernel)
-    chunk_us = kern["chunk_us"]
-    warp_us = kern["warp_us"]
-    R, NW, K = kern["schedule"]
     cnt = load_counters()
+    step_bytes = px * (BYTES_PER_PX_ITER * WARPS * INNER + BYTES_PER_PX_WARP * WARPS)
+    step_px_iters = px * WARPS * INNER
+
+    # ---- the launch-per-chunk path (this run's headline path only for batches; always measured, for comparison)
+    chunk_us, warp_us = kern["chunk_us"], kern["warp_us"]
+    R, NW, K = kern["schedule"]
+    iters_per_launch = WARPS * INNER / float(kern["launches"])
     ck = cnt.get("tvl1_chunk_kernel", {})
     wk = cnt.get("tvl1_warp_kernel", {})
     same = (ck.get("tile") == [R, NW] and ck.get("chunk") == K and ck.get("pairs") == npairs and ck.get("size") == [W, H])
     valu = ck.get("SQ_INSTS_VALU") if same else None
-    traffic = int((2 * ck["FETCH_SIZE_KB"] + ck["WRITE_SIZE_KB"]) * 1024) if same and "FETCH_SIZE_KB" in ck else None
+    traffic = _traffic(ck) if same else None
     algo_bytes = px * BYTES_PER_PX_ITER * iters_per_launch
-    step_bytes = px * (BYTES_PER_PX_ITER * WARPS * INNER + BYTES_PER_PX_WARP * WARPS)
-    # useful pixel-iterations / computed ones: a 64 x TH tile advanced K iterations owns (64-2K) x (TH-2K) pixels
     TH = R * NW
-    own_frac = (64 - 2 * K) * (TH - 2 * K) / float(64 * TH)
-    roof = {"bound": "valu", "kernel": "tvl1_chunk_kernel<%d,%d>" % (R, NW),
-            "achieved": round(valu / (chunk_us * 1e-6) / 1e9, 1) if valu else None,
-            "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
-            "frac": round(valu / (chunk_us * 1e-6) / 1e9 / VALU_PEAK_GINSTR, 4) if valu else None,
-            "traffic": traffic,
-            "launch_us": round(chunk_us, 2),
-            "launch_us_source": "HIP events around whole solves on the library's stream: solve(every launch of this kernel "
-                                "issued twice) - solve, per launch = kernel duration + launch gap",
-            "launch_us_rocprof": ck.get("avg_us") if same else None,
-            "valu_instr_per_launch": valu, "valu_instr_per_useful_px_iter":
-                round(valu * 64 / (px * iters_per_launch), 1) if valu else None,
-            "owned_over_computed_px": round(own_frac, 3),
-            "inner_iters_per_launch": round(iters_per_launch, 2),
-            "counters_file": os.path.relpath(COUNTERS_JSON, ROOT) if same else None,
-            "note": "register-resident temporal blocking: the kernel is bound by vector-ALU issue, not by HBM "
-                    "(see roofline_hbm for the HBM view the north star asks for)"}
-    hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "chunk_kernel": {
-               "algorithmic_bytes_per_launch": int(algo_bytes),
-               "effective_GBps": round(algo_bytes / (chunk_us * 1e-6) / 1e9, 1),
-               "effective_frac": round(algo_bytes / (chunk_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-               "measured_traffic_bytes_per_launch": traffic,
-               "measured_GBps": round(traffic / (chunk_us * 1e-6) / 1e9, 1) if traffic else None,
-               "measured_frac": round(traffic / (chunk_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-               "note": "effective = 76 B/px/iteration x pixels x iterations per launch / launch time; it may exceed the "
-                       "peak because %d iterations run from registers per pass over HBM" % K},
-           "warp_kernel": {
-               "launch_us": round(warp_us, 2), "launch_us_rocprof": wk.get("avg_us"),
-               "algorithmic_bytes_per_launch": int(px * BYTES_PER_PX_WARP),
-               "GBps": round(px * BYTES_PER_PX_WARP / (warp_us * 1e-6) / 1e9, 1) if warp_us > 0 else None,
-               "frac": round(px * BYTES_PER_PX_WARP / (warp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if warp_us > 0 else None,
-               "measured_traffic_bytes_per_launch":
-                   int((2 * wk["FETCH_SIZE_KB"] + wk["WRITE_SIZE_KB"]) * 1024) if "FETCH_SIZE_KB" in wk else None},
-           "whole_step": {
-               "algorithmic_bytes": int(step_bytes), "ms": round(kern["solve_ms"], 3),
-               "effective_GBps": round(step_bytes / (kern["solve_ms"] * 1e-3) / 1e9, 1),
-               "effective_frac": round(step_bytes / (kern["solve_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    per_launch = {
+        "kernel": "tvl1_chunk_kernel<%d,%d>" % (R, NW), "bound": "valu",
+        "achieved": round(valu / (chunk_us * 1e-6) / 1e9, 1) if valu else None, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+        "frac": round(valu / (chunk_us * 1e-6) / 1e9 / VALU_PEAK_GINSTR, 4) if valu else None,
+        "traffic": traffic, "launch_us": round(chunk_us, 2), "launch_us_rocprof": ck.get("avg_us") if same else None,
+        "launch_us_source": "HIP events around whole solves: solve(every launch of this kernel issued twice) - solve, per launch "
+                            "= kernel duration + launch gap",
+        "valu_instr_per_launch": valu,
+        "valu_instr_per_useful_px_iter": round(valu * 64 / (px * iters_per_launch), 1) if valu else None,
+        "owned_over_computed_px": round((64 - 2 * K) * (TH - 2 * K) / float(64 * TH), 3),
+        "inner_iters_per_launch": round(iters_per_launch, 2), "solve_ms": round(kern["solve_ms"], 3),
+        "warp_kernel_us": round(warp_us, 2), "warp_kernel_us_rocprof": wk.get("avg_us"),
+        "hbm": {"algorithmic_bytes_per_launch": int(algo_bytes),
+                "effective_GBps": round(algo_bytes / (chunk_us * 1e-6) / 1e9, 1),
+                "measured_traffic_bytes_per_launch": traffic,
+                "measured_frac": round(traffic / (chunk_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "warp_kernel_GBps": round(px * BYTES_PER_PX_WARP / (warp_us * 1e-6) / 1e9, 1) if warp_us > 0 else None,
+                "warp_kernel_measured_traffic": _traffic(wk)}}
+
+    if pers:
+        # ---- the persistent kernel: the whole schedule in one launch
+        R, NW, K = pers["schedule"]
+        TH, HY = R * NW, ((K + R - 1) // R) * R
+        pk = cnt.get("tvl1_persist_kernel", {})
+        same = (pk.get("tile") == [R, NW] and pk.get("chunk") == K and pk.get("pairs") == npairs and pk.get("size") == [W, H]
+                and pk.get("schedule") == [WARPS, INNER])
+        valu = pk.get("SQ_INSTS_VALU") if same else None
+        traffic = _traffic(pk) if same else None
+        kus = pers["kernel_ms"] * 1e3
+        roof = {"bound": "valu", "kernel": "tvl1_persist_kernel<%d,%d>" % (R, NW),
+                "achieved": round(valu / (kus * 1e-6) / 1e9, 1) if valu else None,
+                "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+                "frac": round(valu / (kus * 1e-6) / 1e9 / VALU_PEAK_GINSTR, 4) if valu else None,
+                "traffic": traffic,
+                "launch_us": round(kus, 1),
+                "launch_us_source": "HIP event pair around the launch, on the library's stream (one launch = one whole solve)",
+                "launch_us_rocprof": pk.get("avg_us") if same else None,
+                "valu_instr_per_launch": valu,
+                "valu_instr_per_useful_px_iter": round(valu * 64 / step_px_iters, 1) if valu else None,
+                "owned_over_computed_px": round((64 - 2 * K) * (TH - 2 * HY) / float(64 * TH), 3),
+                "inner_iters_per_launch": WARPS * INNER, "iters_between_halo_exchanges": K,
+                "us_per_warp": round(kus / WARPS, 2),
+                "counters_file": os.path.relpath(COUNTERS_JSON, ROOT) if same else None,
+                "note": "every tile stays in registers for the whole solve; workgroups exchange halos through HBM every %d "
+                        "iterations.  Bound by vector-ALU issue, not by HBM (roofline_hbm is the view the north star asks for); "
+                        "achieved counts EXECUTED instructions, halo recomputation included" % K}
+        hbm_kernel = {"kernel": roof["kernel"], "algorithmic_bytes_per_launch": int(step_bytes),
+                      "effective_GBps": round(step_bytes / (kus * 1e-6) / 1e9, 1),
+                      "effective_frac": round(step_bytes / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                      "measured_traffic_bytes_per_launch": traffic,
+                      "measured_GBps": round(traffic / (kus * 1e-6) / 1e9, 1) if traffic else None,
+                      "measured_frac": round(traffic / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                      "note": "effective = (76 B/px/iteration x iterations + 44 B/px/warp x warps) x pixels / launch time: what a "
+                              "kernel streaming every plane once per iteration would move; it may exceed the peak because the "
+                              "state never leaves the registers -- measured = what the counters saw"}
+        solve_ms = pers["solve_ms"]
+    else:
+        roof = dict(per_launch)
+        roof.pop("hbm")
+        roof["counters_file"] = os.path.relpath(COUNTERS_JSON, ROOT) if valu else None
+        roof["note"] = ("register-resident temporal blocking: the kernel is bound by vector-ALU issue, not by HBM "
+                        "(see roofline_hbm for the HBM view the north star asks for)")
+        hbm_kernel = dict(per_launch["hbm"], kernel=per_launch["kernel"])
+        solve_ms = kern["solve_ms"]
+    hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "dominant_kernel": hbm_kernel,
+           "whole_step": {"algorithmic_bytes": int(step_bytes), "ms": round(solve_ms, 3),
+                          "effective_GBps": round(step_bytes / (solve_ms * 1e-3) / 1e9, 1),
+                          "effective_frac": round(step_bytes / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
     if roof["frac"] is not None:
         assert roof["frac"] <= 1.0, "VALU roofline fraction above 1: counters file does not belong to this kernel"
     return {
@@ -311,10 +360,12 @@ def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, dev_
                                % (npairs, W, H, WARPS, INNER,
                                   "; %d pairs over %d GPUs = configs[3] shape" % (npairs * world, world) if world > 1 else ""),
                    "pairs_per_gpu": npairs, "parallelism": "pairs-sharded x%d" % world,
-                   "ranks": len(per_rank), "collectives": "RCCL barrier + MAX/SUM of two scalars; none on the data path"},
+                   "ranks": len(per_rank), "collectives": "RCCL barrier + MAX/SUM of two scalars; none on the data path",
+                   "kernel_path": "persistent (one launch per solve)" if pers else "one launch per chunk of iterations"},
         "per_rank_Mpx_iter_per_s": [round(v, 1) for v in per_rank],
         "roofline": roof, "roofline_hbm": hbm,
-        "solve_us_per_launch_incl_warp_kernel": round(group_us, 2),
+        "per_launch_path": per_launch if pers else None,
+        "launches_per_step": launches / float(args.steps),
     }
 
 

@@ -18,6 +18,7 @@ import os
 import re
 
 FAMILIES = {            # JSON key -> substring of the demangled kernel name
+    "tvl1_persist_kernel": "tvl1_persist_kernel",
     "tvl1_chunk_kernel": "tvl1_chunk_kernel",
     "tvl1_warp_kernel": "tvl1_warp_kernel",
     "nl_primal_kernel": "nl_primal_kernel",
@@ -40,6 +41,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--label", default="")
     ap.add_argument("--chunk-tile", default="", help="R,NW,chunk,pairs,W,H of the chunk kernel's schedule in these runs")
+    ap.add_argument("--persist-tile", default="", help="R,NW,k,pairs,WxH,warps,inner of the persistent kernel's schedule in these runs")
     ap.add_argument("--grid", action="append", default=[], metavar="FAMILY=THREADS",
                     help="count only the dispatches of FAMILY whose grid has THREADS work-items (the bench's secondary legs launch the "
                          "same kernels on other sizes)")
@@ -94,6 +96,9 @@ def main():
     if a.chunk_tile and "tvl1_chunk_kernel" in out:
         r, nw, k, pairs, w, h = (int(x) for x in re.split("[,x]", a.chunk_tile))
         out["tvl1_chunk_kernel"].update({"tile": [r, nw], "chunk": k, "pairs": pairs, "size": [w, h]})
+    if a.persist_tile and "tvl1_persist_kernel" in out:
+        r, nw, k, pairs, w, h, warps, inner = (int(x) for x in re.split("[,x]", a.persist_tile))
+        out["tvl1_persist_kernel"].update({"tile": [r, nw], "chunk": k, "pairs": pairs, "size": [w, h], "schedule": [warps, inner]})
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -2,12 +2,14 @@
 # Profiles the bench command on the GPU box: one duration pass and separate counter passes (the microarchitecture
 # guide: FETCH_SIZE and WRITE_SIZE cannot share a pass; counters only next to --kernel-trace), then reduces them ON
 # THE BOX to profiles-style summaries (the raw per-dispatch CSVs are tens of MB per pass and are deleted).
-#   bash tools/profile_bench.sh r02 "<bench args>" "<R,NW,chunk,pairs,WxH of the chunk kernel's schedule>"
+#   bash tools/profile_bench.sh r02 "<bench args>" "<R,NW,chunk,pairs,WxH of the chunk kernel's schedule>" \
+#        "<R,NW,k,pairs,WxH,warps,inner of the persistent kernel's schedule>"
 #   -> gpurun_out/prof_r02/{counters.json, kernel_stats.csv, *.log}
 set -e
 TAG=${1:-r02}
 ARGS=${2:---steps 3 --warmup 1 --no-cpu-baseline}
 TILE=${3:-4,16,10,1,1024x436}
+PTILE=${4:-3,16,5,1,1024x436,300,10}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
@@ -18,8 +20,8 @@ run sq2 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_
 run sq3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run fetch --kernel-trace --pmc FETCH_SIZE
 run write --kernel-trace --pmc WRITE_SIZE
-python3 tools/pmc_summary.py --out $OUT/counters.json --label "$TAG: python3 bench.py $ARGS" --chunk-tile "$TILE" \
-    --grid tvl1_chunk_kernel=245760 --grid tvl1_warp_kernel=446464 --grid nl_dual_kernel=446464 --grid nl_primal_kernel=446464 \
+python3 tools/pmc_summary.py --out $OUT/counters.json --label "$TAG: python3 bench.py $ARGS" --chunk-tile "$TILE" --persist-tile "$PTILE" \
+    --grid tvl1_persist_kernel=253952 --grid tvl1_chunk_kernel=245760 --grid tvl1_warp_kernel=446464 --grid nl_dual_kernel=446464 --grid nl_primal_kernel=446464 \
     $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/fetch $OUT/write
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 rm -rf $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/fetch $OUT/write
