@@ -397,7 +397,48 @@ def case_growing_m(rng):
     return ok, desc
 
 
-FAMILIES = {"growing_m": case_growing_m, "tvl1_batch": case_tvl1_batch, "growing_big": case_growing_big, "tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv,
+def case_persist(rng):
+    """A static schedule of one pair on the persistent kernel (random tile geometry, ragged last tiles, many tiles) against
+    the launch-per-chunk path: same flow, duals, errors bit for bit; where a NaN was injected, the same NaN set (a NaN's payload
+    is not pinned anywhere: the two kernels are compiled separately and may commute the operands of an addition)."""
+    w, h = int(rng.integers(2, 1100)), int(rng.integers(2, 480))
+    if rng.random() < 0.4:
+        w, h = int(rng.integers(2, 200)), int(rng.integers(2, 140))
+    i0n, i1n, gt = util.synthetic_pair(max(w, 4), max(h, 4), seed=int(rng.integers(1 << 30)), amp=float(rng.uniform(0, 8)))
+    i0n, i1n, gt = np.ascontiguousarray(i0n[:h, :w]), np.ascontiguousarray(i1n[:h, :w]), np.ascontiguousarray(gt[:, :h, :w])
+    u0 = (gt * float(rng.choice([0.0, 0.5, 1.0])) + rng.normal(0, float(rng.choice([0, 0.5, 20.0])), (2, h, w))).astype(np.float32)
+    if rng.random() < 0.15:
+        u0[int(rng.integers(0, 2)), int(rng.integers(0, h)), int(rng.integers(0, w))] = np.nan
+    xi = (rng.normal(0, float(rng.choice([0.3, 2.0])), (4, h, w))).astype(np.float32) if rng.random() < 0.5 else None
+    prm = dict(warps=int(rng.integers(1, 6)), max_inner=int(rng.integers(1, 24)), tol_stop=0,
+               lambda_=float(rng.choice([40.0, 10.0, 0.5, 120.0])), theta=float(rng.choice([0.3, 0.1, 0.8])),
+               tau=float(rng.choice([0.125, 0.25, 0.05])), chunk=int(rng.choice([0, 0, 0, 1, 2, 3, 4, 6, 8])))
+    cfg = str(rng.choice(["", "", "3,16,5", "4,13,5", "4,11,4", "4,16,8", "3,14,3", "3,16,2", "4,16,4"]))
+    res = []
+    for persist in ("0", "1"):
+        os.environ["FALDOI_PERSIST"] = persist
+        if cfg and persist == "1":
+            os.environ["FALDOI_PERSIST_CFG"] = cfg
+        else:
+            os.environ.pop("FALDOI_PERSIST_CFG", None)
+        b = F.Tvl1Batch(ctx, 1, w, h)
+        try:
+            b.upload(0, i0n, i1n, u0, xi)
+            its, errs, _, launches = b.solve(**prm)
+            u, x = b.download(0, want_xi=True)
+            res.append((u, x, its.copy(), errs.copy(), launches, b.last_persistent()))
+        finally:
+            b.close()
+    os.environ.pop("FALDOI_PERSIST", None)
+    os.environ.pop("FALDOI_PERSIST_CFG", None)
+    r, n = res
+    ok = same_up_to_nan_payload(r[0], n[0]) and same_up_to_nan_payload(r[1], n[1]) and np.array_equal(r[2], n[2]) and \
+        same_up_to_nan_payload(r[3], n[3]) and not r[5]
+    desc = "%dx%d cfg=%r persistent=%s launches %d->%d %s xi=%s" % (w, h, cfg, n[5], r[4], n[4], prm, xi is not None)
+    return ok, desc
+
+
+FAMILIES = {"persist": case_persist, "growing_m": case_growing_m, "tvl1_batch": case_tvl1_batch, "growing_big": case_growing_big, "tvl1": case_tvl1, "growing": case_growing, "tvcsad": case_tvcsad, "nltv": case_nltv,
             "growing_edge": case_growing_edge, "batch": case_batch, "batch_split": case_batch_split, "prims": case_prims, "tvl1_nan": case_tvl1_nan}
 fams = [f for f in a.family.split(",") if f]
 t_end = time.time() + a.minutes * 60
