@@ -746,6 +746,19 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
             }
             if (cnt) fprintf(stderr, "   %-42s %6.2f / %6.2f\n", name[j], sum / cnt, mx);
         }
+        if (atoi(getenv("FALDOI_STAMPS")) > 1) {                      // per tile: warp constants | both chunks' iterations | whole warp
+            for (int pass = 0; pass < 3; ++pass) {
+                fprintf(stderr, "%s\n", pass == 0 ? "warp constants (us), tile grid:" : pass == 1 ? "iterations of the warp (us):" : "whole warp (us):");
+                for (int ty = 0; ty < nty; ++ty) {
+                    for (int tx = 0; tx < ntx; ++tx) {
+                        const unsigned long long *q = &hs[(size_t)kPersistStamps * (ty * ntx + tx)];
+                        const double v = pass == 0 ? (double)(q[1] - q[0]) : pass == 1 ? (double)(q[5] - q[4]) + (double)(q[11] - q[10]) : (double)(q[6] - q[0]);
+                        fprintf(stderr, "%5.1f", v * 0.01);
+                    }
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
     }
     if (d_stamps) {
         std::vector<unsigned long long> hs((size_t)4 * total_tiles);
