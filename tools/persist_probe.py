@@ -83,6 +83,7 @@ def headline(ctx, cfgs, stamps):
                 os.environ.pop("FALDOI_STAMPS")
         except RuntimeError as e:
             print("persistent %-8s: %s" % (cfg, e), flush=True)
+    b.close()
 
 
 if __name__ == "__main__":

@@ -53,6 +53,7 @@ def one(v, cfg):
                 b.solve(warps=300, max_inner=10, tol_stop=0)
             res.append(min(b.solve(warps=300, max_inner=10, tol_stop=0)[2] for _ in range(5)))
         print("%-40s per-launch %7.3f ms   persistent %7.3f ms" % (VARIANTS[v], res[0], res[1]), flush=True)
+        b.close()
 
 
 if __name__ == "__main__":
