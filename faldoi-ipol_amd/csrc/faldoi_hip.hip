@@ -746,6 +746,14 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
             }
             if (cnt) fprintf(stderr, "   %-42s %6.2f / %6.2f\n", name[j], sum / cnt, mx);
         }
+        {
+            double cyc = 0, ref = 0;                                     // shader clock (s_memtime) against the constant 100 MHz clock
+            for (int q = 0; q < ntiles; ++q) {
+                const unsigned long long *v = &hs[(size_t)kPersistStamps * q];
+                if (v[14] > v[13] && v[6] > v[0]) { cyc += (double)(v[14] - v[13]); ref += (double)(v[6] - v[0]); }
+            }
+            if (ref > 0) fprintf(stderr, "   shader clock during that warp: %.0f MHz\n", cyc / ref * 100.0);
+        }
         if (atoi(getenv("FALDOI_STAMPS")) > 1) {                      // per tile: warp constants | both chunks' iterations | whole warp
             for (int pass = 0; pass < 3; ++pass) {
                 fprintf(stderr, "%s\n", pass == 0 ? "warp constants (us), tile grid:" : pass == 1 ? "iterations of the warp (us):" : "whole warp (us):");

@@ -140,7 +140,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
     for (int w = 0; w < a.prm.warps; ++w) {
         const bool stamp = a.stamps && w == a.stamp_warp && threadIdx.x == 0;
         unsigned long long *st = a.stamps + (size_t)t * kPersistStamps;
-        if (stamp) st[0] = __builtin_amdgcn_s_memrealtime();
+        if (stamp) { st[0] = __builtin_amdgcn_s_memrealtime(); st[13] = __builtin_amdgcn_s_memtime(); }
         // ---- the warp constants of the owned pixels (src/global_faldoi.cpp:635-657; tvl1_warp_kernel) ----
         // (dealing the owned pixels to all threads through LDS, two pixels each instead of R for the owners and none for the
         // halo, was measured: no faster -- the phase is bound by its ~530 vector instructions per pixel, not by their spread)
@@ -295,7 +295,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;   // the same wave that read row i
             n += it;
         }
-        if (stamp) st[6] = __builtin_amdgcn_s_memrealtime();
+        if (stamp) { st[6] = __builtin_amdgcn_s_memrealtime(); st[14] = __builtin_amdgcn_s_memtime(); }
     }
 
     // ---- the solved state of the owned pixels (ubar is dead after the last warp) ----
