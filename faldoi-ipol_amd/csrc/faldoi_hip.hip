@@ -246,17 +246,19 @@ static bool tile_supported(int r, int w)
 
 // Tile shape and iterations per launch.  Measured on MI355X (tests/tools/sweep.py, 1024x436 pairs):
 //   * while the 64x64 / k=10 tiling yields at most one tile per CU (a single pair of this size:
-//     240 tiles on 256 CUs) it is the fastest -- fewest launches, all CUs busy once;
-//   * with more tiles than CUs (batches, large frames) occupancy is no longer the constraint and
-//     the halo redundancy is: 64x36 tiles advanced 5 iterations per launch computed 1.5x instead of
-//     2.2x the useful pixels and ran 16-27 % faster (2-8 pairs per GPU).
+//     240 tiles on 256 CUs) it is the fastest of the launch-per-chunk schedules -- fewest launches, all CUs busy once
+//     (a static schedule of such a job runs on the persistent kernel instead, pick_persist);
+//   * with more tiles than CUs (batches, large frames) occupancy is no longer the constraint, the halo redundancy and
+//     the overlap between workgroups are: 64x32 tiles of 512 threads (two workgroups per CU, each with its own barriers)
+//     advanced 5 iterations per launch: 114 / 121 / 135 / 144 Gpx*iter/s at 2 / 3 / 4 / 8 pairs per GPU (round 2; the
+//     64x36 tiles of 768 threads used before: 96 / 108 / 106 / 114).
 // An explicit params.chunk or FALDOI_TILE=R,NW (tuning aid) overrides the choice.
 static void pick_schedule(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, TileCfg *tc, int *chunk)
 {
     const int S = kTileW - 20;                                  // owned pixels per 64-wide tile at k = 10
     const long tiles_big = (long)((b->nx + S - 1) / S) * ((b->ny + S - 1) / S) * b->npairs;
     const bool small_job = tiles_big <= b->ctx->n_cu;
-    *tc = small_job ? TileCfg{4, 16} : TileCfg{3, 12};
+    *tc = small_job ? TileCfg{4, 16} : TileCfg{4, 8};
     int k = prm->chunk ? prm->chunk : (small_job ? 10 : 5);
     if (const char *s = getenv("FALDOI_TILE")) {
         int r = 0, w = 0;
