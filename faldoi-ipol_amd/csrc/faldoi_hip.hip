@@ -6,6 +6,7 @@
 #include "faldoi_hip.h"
 #include "tvl1_kernels.hpp"
 #include "tvl1_persist_kernel.hpp"
+#include "tvl1_persist_dyn_kernel.hpp"
 #include "preprocess_kernels.hpp"
 #include "nltv_kernels.hpp"
 #include "local_kernels.hpp"
@@ -140,7 +141,7 @@ struct faldoi_tvl1_batch {
     std::vector<hipEvent_t> ev;       // per-launch event pairs (only when FALDOI_EVENT_TIMING=1)
     float *xslab = nullptr;           // halo exchange slabs of the persistent kernel (tvl1_persist_kernel.hpp)
     size_t xslab_bytes = 0;
-    unsigned *xflags = nullptr;       // its epoch flags + abort word
+    unsigned *xflags = nullptr;       // its epoch flags + abort word, then the error boards of the tolerance-stop form
     size_t xflags_bytes = 0;
     int last_persistent = 0;
     bool persist_off = false;         // the persistent kernel once gave up on this batch (its workgroups were not all resident)
@@ -332,7 +333,8 @@ static bool persist_fits(const faldoi_tvl1_batch *b, int R, int NW, int k, Persi
     const int Sx = kTileW - 2 * k, Sy = R * NW - 2 * hy;
     if (Sx < k || Sy < hy || Sx < 8 || Sy < R) return false;            // a halo reaches the adjacent tile only
     const long tiles = (long)((b->nx + Sx - 1) / Sx) * ((b->ny + Sy - 1) / Sy);
-    if (tiles > b->ctx->n_cu) return false;                               // every workgroup resident, one per CU
+    if (tiles > b->ctx->n_cu || tiles > 256) return false;                // every workgroup resident, one per CU (256: a wave reads the
+                                                                          // tolerance-stop kernel's error board four tiles per lane)
     *out = PersistCfg{ R, NW, k, hy };
     return true;
 }
@@ -342,11 +344,13 @@ static bool pick_persist(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *p
     if (const char *on = getenv("FALDOI_PERSIST"))                        // FALDOI_PERSIST=0: always the per-launch path
         if (atoi(on) <= 0) return false;
     if (b->persist_off) return false;                                     // a launch of this batch timed out before
-    if (prm->tol_stop != 0 || b->npairs != 1) return false;
+    if (b->npairs != 1) return false;
+    const bool dynamic = prm->tol_stop != 0;                              // tvl1_persist_dyn_kernel.hpp: built for 64x48 tiles only
     if (const char *s = getenv("FALDOI_PERSIST_CFG")) {                   // tuning aid: R,NW,k
         int r = 0, w = 0, k = 0;
-        if (sscanf(s, "%d,%d,%d", &r, &w, &k) == 3 && persist_supported(r, w)) {
+        if (sscanf(s, "%d,%d,%d", &r, &w, &k) == 3 && persist_supported(r, w) && (!dynamic || (r == 3 && w == 16))) {
             if (k > prm->max_inner) k = prm->max_inner;
+            if (dynamic && k > 8) return false;
             return persist_fits(b, r, w, k, out);
         }
         return false;
@@ -358,8 +362,9 @@ static bool pick_persist(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *p
     for (const auto &c : cand) {
         int k = prm->chunk ? prm->chunk : c[2];
         if (k > prm->max_inner) k = prm->max_inner;
+        if (dynamic && k > 8) return false;                                // its error board is read eight entries per tile
         if (persist_fits(b, c[0], c[1], k, out)) return true;
-        if (!prm->chunk) break;
+        if (!prm->chunk || dynamic) break;
     }
     return false;
 }
@@ -378,6 +383,17 @@ static hipError_t launch_persist(const PersistCfg &pc, dim3 grid, hipStream_t s,
     FALDOI_CASE(4, 11)
 #undef FALDOI_CASE
     return hipErrorInvalidValue;
+}
+
+static hipError_t launch_persist_dyn(const PersistCfg &pc, dim3 grid, hipStream_t s, const PersistArgs &a)
+{
+    if (pc.R != 3 || pc.NW != 16) return hipErrorInvalidValue;
+    const size_t lds = 8ull * 3 * 64 * 16 * sizeof(float);             // the snapshot: 96 KB beside 21 KB static (160 KB per CU)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&tvl1_persist_dyn_kernel<3, 16>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((tvl1_persist_dyn_kernel<3, 16>), grid, dim3(64 * 16), lds, s, a);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------ batch
@@ -602,7 +618,8 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     unsigned long long *p_stamps_out = nullptr;
     if (persist) {
         const size_t slab_bytes = 2ull * ntiles * kXPlanes * tc.NW * kTileW * 16ull;
-        const size_t flag_bytes = ((size_t)ntiles + 1) * kFlagStride * sizeof(unsigned);
+        const size_t flag_words = ((size_t)ntiles + 1) * kFlagStride;    // epoch flags, abort word
+        const size_t flag_bytes = (flag_words + (dynamic ? 2ull * ntiles * kMaxChunk : 0)) * sizeof(unsigned);   // + two error boards
         if (slab_bytes >= (1ull << 32)) return fail(FALDOI_ERR_STATE, "exchange slab of %zu bytes", slab_bytes);
         int rc = ensure((void **)&b->xslab, &b->xslab_bytes, slab_bytes);
         if (rc) return rc;
@@ -629,20 +646,25 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         if (const char *v = getenv("FALDOI_PERSIST_SPINS")) { const long q = atol(v); if (q > 0 && q < (1L << 31)) a.spin_limit = (unsigned)q; }
         a.stamps = p_stamps;
         a.stamp_warp = warps / 2;
+        a.err_board = b->xflags + flag_words;
+        a.iters_out = b->d_iters;
+        a.werr_out = b->d_err;
         while (b->ev.size() < 2) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
             b->ev.push_back(e);
         }
         HIP_TRY(hipEventRecord(b->ev[0], s));
-        HIP_TRY(launch_persist(pc, grid, s, a));
+        HIP_TRY(dynamic ? launch_persist_dyn(pc, grid, s, a) : launch_persist(pc, grid, s, a));
         HIP_TRY(hipEventRecord(b->ev[1], s));
         ev_used = 2;
         launches = 1;
-        const int rem = prm->max_inner % chunk;
-        hipLaunchKernelGGL(tvl1_static_stats_kernel, dim3(warps * b->npairs), dim3(256), 0, s, b->err_part, ntiles,
-                           b->npairs, warps, prm->max_inner, rem ? rem : chunk, b->d_iters, b->d_err);
-        HIP_TRY(hipGetLastError());
+        if (!dynamic) {                                            // (the tolerance-stop kernel writes iterations and errors itself)
+            const int rem = prm->max_inner % chunk;
+            hipLaunchKernelGGL(tvl1_static_stats_kernel, dim3(warps * b->npairs), dim3(256), 0, s, b->err_part, ntiles,
+                               b->npairs, warps, prm->max_inner, rem ? rem : chunk, b->d_iters, b->d_err);
+            HIP_TRY(hipGetLastError());
+        }
         b->final_cur[0] = 1;
         HIP_TRY(hipMemcpyAsync(c->h_done, b->xflags + (size_t)ntiles * kFlagStride, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         p_stamps_out = p_stamps;

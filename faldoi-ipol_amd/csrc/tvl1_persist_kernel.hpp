@@ -48,6 +48,10 @@ struct PersistArgs {
     unsigned spin_limit;
     unsigned long long *stamps;    // optional: [ntiles][kPersistStamps], taken during warp `stamp_warp`
     int stamp_warp;
+    // tolerance stop on (tvl1_persist_dyn_kernel.hpp) only:
+    unsigned *err_board;           // [2][ntiles][kMaxChunk] per-iteration tile maxima of the chunk just iterated (float bits)
+    int *iters_out;                // [warps] iterations each warp ran, as the reference's `Warping: w,Iter: n` line
+    float *werr_out;               // [warps] its last max |du|^2
 };
 
 template <int R>
@@ -69,61 +73,57 @@ __device__ __forceinline__ void unpack_rows(float (&v)[R], const xvec4 o, bool t
     if (R > 3) v[R > 3 ? 3 : 0] = take ? __uint_as_float(o.w) : v[R > 3 ? 3 : 0];
 }
 
-template <int R, int NW, int BORDER>
-__device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, int txi, int tyi,
-                                                  float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
-                                                  float (*s_x22)[kTileW], unsigned (*s_err)[kTileW], int *s_ctl)
+// ---- pieces shared by the static body below and the tolerance-stop body (tvl1_persist_dyn_kernel.hpp) ----
+
+// Where a thread sits: tile = 64 columns x R*NW rows, halo hx columns / hy rows; lane = column, wave w = rows [wR, wR+R).
+struct PxGeom {
+    int gx, gy0;                   // image column; first image row of the thread's R rows (wave-uniform, a multiple of R)
+    bool col_in, wave_live;        // column inside the image; the wave has rows inside the image
+    bool owner, halo, ring;        // its pixels are stored by this tile | by another tile | owned and inside a neighbour's footprint
+    unsigned plane_stride, parity_stride;   // exchange slab addressing, in bytes (host: the whole slab is below 4 GB)
+    unsigned pub_off, src_off;     // the thread's own vector in its tile's slab | the owner's vector of its halo pixels
+};
+
+template <int R, int NW>
+__device__ __forceinline__ PxGeom px_geometry(const PersistArgs &a, int t, int txi, int tyi, int lane, int wv)
 {
-    static_assert(R >= 2 && R <= 4, "a thread's rows travel as one 16-byte vector");
     constexpr int TH = R * NW;
-    const int nx = a.nx, ny = a.ny, ntx = a.ntx, nty = a.nty;
-    const int ntiles = ntx * nty;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Sx = kTileW - 2 * a.hx, Sy = TH - 2 * a.hy;
-    const int gx = txi * Sx - a.hx + lane;
-    const int gy0 = tyi * Sy - a.hy + wv * R;           // scalar; a multiple of R (hy and Sy are): a thread's rows share their owner
-    const bool col_in = gx >= 0 && gx < nx;
-    const bool col_own = col_in && gx >= txi * Sx && gx < (txi + 1) * Sx;
-    const bool group_in = gy0 >= 0 && gy0 < ny;
-    const bool group_own = group_in && gy0 >= tyi * Sy && gy0 < (tyi + 1) * Sy;
-    const bool wave_live = group_in;
-    const bool owner = col_own && group_own;
-    const bool halo = col_in && group_in && !owner;
-    // owned pixels a neighbour's footprint covers
-    const bool ring = owner && (gx - txi * Sx < a.hx || (txi + 1) * Sx - 1 - gx < a.hx || gy0 - tyi * Sy < a.hy ||
-                                (tyi + 1) * Sy - (gy0 + R) < a.hy);
-
-    // exchange slab addressing, in bytes (host: the whole slab is below 4 GB)
-    const unsigned plane_stride = (unsigned)(NW * kTileW) * 16u;
-    const unsigned tile_stride = plane_stride * (unsigned)kXPlanes;
-    const unsigned parity_stride = tile_stride * (unsigned)ntiles;
-    const unsigned pub_off = (unsigned)t * tile_stride + (unsigned)(wv * kTileW + lane) * 16u;
-    unsigned src_off = 0;
-    if (halo) {
-        const int txp = gx / Sx, typ = gy0 / Sy;
-        const int lane_p = gx - txp * Sx + a.hx, wave_p = (gy0 - typ * Sy + a.hy) / R;
-        src_off = (unsigned)(typ * ntx + txp) * tile_stride + (unsigned)(wave_p * kTileW + lane_p) * 16u;
+    PxGeom g;
+    g.gx = txi * Sx - a.hx + lane;
+    g.gy0 = tyi * Sy - a.hy + wv * R;                  // hy and Sy are multiples of R: a thread's rows share their owner
+    g.col_in = g.gx >= 0 && g.gx < a.nx;
+    const bool col_own = g.col_in && g.gx >= txi * Sx && g.gx < (txi + 1) * Sx;
+    const bool group_in = g.gy0 >= 0 && g.gy0 < a.ny;
+    const bool group_own = group_in && g.gy0 >= tyi * Sy && g.gy0 < (tyi + 1) * Sy;
+    g.wave_live = group_in;
+    g.owner = col_own && group_own;
+    g.halo = g.col_in && group_in && !g.owner;
+    g.ring = g.owner && (g.gx - txi * Sx < a.hx || (txi + 1) * Sx - 1 - g.gx < a.hx || g.gy0 - tyi * Sy < a.hy ||
+                         (tyi + 1) * Sy - (g.gy0 + R) < a.hy);
+    g.plane_stride = (unsigned)(NW * kTileW) * 16u;
+    const unsigned tile_stride = g.plane_stride * (unsigned)kXPlanes;
+    g.parity_stride = tile_stride * (unsigned)(a.ntx * a.nty);
+    g.pub_off = (unsigned)t * tile_stride + (unsigned)(wv * kTileW + lane) * 16u;
+    g.src_off = 0;
+    if (g.halo) {
+        const int txp = g.gx / Sx, typ = g.gy0 / Sy;
+        const int lane_p = g.gx - txp * Sx + a.hx, wave_p = (g.gy0 - typ * Sy + a.hy) / R;
+        g.src_off = (unsigned)(typ * a.ntx + txp) * tile_stride + (unsigned)(wave_p * kTileW + lane_p) * 16u;
     }
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xslab, 0, a.xslab_bytes, 0x00020000);
-    unsigned *abort_word = a.flags + (size_t)ntiles * kFlagStride;
+    return g;
+}
 
-    float *slab = a.base;
-    const float *ini = slab + (size_t)P_STATE0 * a.plane_elems;
-    float *dst = slab + (size_t)P_STATE1 * a.plane_elems;
-    const float *I0 = slab + (size_t)P_I0 * a.plane_elems;
-    const float *I1 = slab + (size_t)P_I1 * a.plane_elems;
-    const float *I1x = slab + (size_t)P_I1X * a.plane_elems;
-    const float *I1y = slab + (size_t)P_I1Y * a.plane_elems;
-
-    TileState<R> s;
-    bool in[R];
+// The uploaded state of the owned pixels (state buffer 0); everything else starts at zero.
+template <int R>
+__device__ __forceinline__ void px_load_owned(TileState<R> &s, const PersistArgs &a, const PxGeom &g)
+{
+    const float *ini = a.base + (size_t)P_STATE0 * a.plane_elems;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int gy = gy0 + r;
-        in[r] = col_in && gy >= 0 && gy < ny;
-        s.own[r] = in[r] && owner;
-        const int p = s.own[r] ? gy * nx + gx : 0;
+        const int gy = g.gy0 + r;
+        s.own[r] = g.owner && gy < a.ny;
+        const int p = s.own[r] ? gy * a.nx + g.gx : 0;
         s.u1[r] = s.own[r] ? ini[0 * a.plane_elems + p] : 0.0f;
         s.u2[r] = s.own[r] ? ini[1 * a.plane_elems + p] : 0.0f;
         s.x11[r] = s.own[r] ? ini[4 * a.plane_elems + p] : 0.0f;
@@ -134,6 +134,192 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
         s.rc[r] = s.ix[r] = s.iy[r] = s.gr[r] = 0.0f;
         s.rgr[r] = 0.0;
     }
+}
+
+// The solved state of the owned pixels into state buffer 1 (ubar is dead after the last warp).
+template <int R>
+__device__ __forceinline__ void px_store_owned(const TileState<R> &s, const PersistArgs &a, const PxGeom &g)
+{
+    float *dst = a.base + (size_t)P_STATE1 * a.plane_elems;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (s.own[r]) {
+            const int p = (g.gy0 + r) * a.nx + g.gx;
+            dst[0 * a.plane_elems + p] = s.u1[r];
+            dst[1 * a.plane_elems + p] = s.u2[r];
+            dst[4 * a.plane_elems + p] = s.x11[r];
+            dst[5 * a.plane_elems + p] = s.x12[r];
+            dst[6 * a.plane_elems + p] = s.x21[r];
+            dst[7 * a.plane_elems + p] = s.x22[r];
+        }
+    }
+}
+
+
+// The warp constants of the thread's owned pixels (src/global_faldoi.cpp:635-657; the code of tvl1_warp_kernel).
+// (Dealing the owned pixels to all threads through LDS, two pixels each instead of R for the owners and none for the halo, was
+// measured: no faster -- the phase is bound by its ~430 vector instructions per pixel, not by their spread.)
+template <int R>
+__device__ __forceinline__ void px_warp_constants(TileState<R> &s, const float *__restrict__ I0, const float *__restrict__ I1,
+                                                  const float *__restrict__ I1x, const float *__restrict__ I1y, int gx, int gy0,
+                                                  int nx, int ny)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float rc = 0.0f, wx = 0.0f, wy = 0.0f;                   // the halo's constants arrive with the exchange
+        if (!(kWhatIf & 32) && s.own[r]) {
+            const int gy = gy0 + r;
+            float i0v = I0[gy * nx + gx];
+            asm volatile("" : "+v"(i0v));
+            const float uu = (float)gx + s.u1[r];                // src/bicubic_interpolation.c:259-260
+            const float vv = (float)gy + s.u2[r];
+            const BicubicTaps tp = bicubic_taps(uu, vv, nx, ny);
+            float w0 = 0.0f;                                     // border_out = true (:635-637)
+            if (!tp.clamped) {
+                w0 = bicubic_eval_rows(I1, tp, nx);
+                wx = bicubic_eval_rows(I1x, tp, nx);
+                wy = bicubic_eval_rows(I1y, tp, nx);
+            }
+            rc = rho_const(w0, wx, wy, s.u1[r], s.u2[r], i0v);
+        }
+        s.rc[r] = rc;
+        s.ix[r] = wx;
+        s.iy[r] = wy;
+    }
+}
+
+// Publish: write-through, one 16-byte vector (the thread's R rows) per plane.  `first`: the exchange at a warp's start carries the
+// warp constants and no ubar (ubar = u there, :659-660).  Called by the threads of the ring only.
+template <int R, typename RSRC>
+__device__ __forceinline__ void px_publish(const TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride, bool first)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u1), rsrc, base + 0u * plane_stride, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u2), rsrc, base + 1u * plane_stride, 0, 16);
+    if (!first) {
+        __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub1), rsrc, base + 2u * plane_stride, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub2), rsrc, base + 3u * plane_stride, 0, 16);
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x11), rsrc, base + 4u * plane_stride, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x12), rsrc, base + 5u * plane_stride, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x21), rsrc, base + 6u * plane_stride, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x22), rsrc, base + 7u * plane_stride, 0, 16);
+    if (first) {
+        __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.rc), rsrc, base + 8u * plane_stride, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ix), rsrc, base + 9u * plane_stride, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.iy), rsrc, base + 10u * plane_stride, 0, 16);
+    }
+}
+
+// Fetch the halo from its owners' slabs (sc1 loads only); at a warp's start also ubar = u and the per-warp |grad I|^2.
+template <int R, typename RSRC>
+__device__ __forceinline__ void px_fetch(TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride, bool halo, bool first)
+{
+    xvec4 q[kXPlanes];
+#pragma unroll
+    for (int k = 0; k < kXPlanes; ++k) q[k] = xvec4{ 0u, 0u, 0u, 0u };
+    if (halo) {
+        q[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 0u * plane_stride, 0, 16);
+        q[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 1u * plane_stride, 0, 16);
+        if (!first) {
+            q[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 2u * plane_stride, 0, 16);
+            q[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 3u * plane_stride, 0, 16);
+        }
+        q[4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 4u * plane_stride, 0, 16);
+        q[5] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 5u * plane_stride, 0, 16);
+        q[6] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 6u * plane_stride, 0, 16);
+        q[7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 7u * plane_stride, 0, 16);
+        if (first) {
+            q[8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 8u * plane_stride, 0, 16);
+            q[9] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 9u * plane_stride, 0, 16);
+            q[10] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 10u * plane_stride, 0, 16);
+        }
+    }
+    unpack_rows<R>(s.u1, q[0], halo);
+    unpack_rows<R>(s.u2, q[1], halo);
+    unpack_rows<R>(s.ub1, q[2], halo && !first);
+    unpack_rows<R>(s.ub2, q[3], halo && !first);
+    unpack_rows<R>(s.x11, q[4], halo);
+    unpack_rows<R>(s.x12, q[5], halo);
+    unpack_rows<R>(s.x21, q[6], halo);
+    unpack_rows<R>(s.x22, q[7], halo);
+    unpack_rows<R>(s.rc, q[8], halo && first);
+    unpack_rows<R>(s.ix, q[9], halo && first);
+    unpack_rows<R>(s.iy, q[10], halo && first);
+    if (first) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            s.ub1[r] = s.u1[r];                                    // start of a warp: ubar = u (:659-660)
+            s.ub2[r] = s.u2[r];
+            s.gr[r] = grad_sq(s.ix[r], s.iy[r]);                   // :648-652
+            s.rgr[r] = recip_f64(s.gr[r]);
+        }
+    }
+}
+
+// One wave waits until every neighbour (lanes 0..7 one each; `all`: every tile of the grid, lane by lane) has published `epoch`;
+// lane 8 (`all`: an extra load by lane 0) watches the abort word.  Bounded: returns true when the workgroup must leave.
+__device__ __forceinline__ bool px_wait(const unsigned *flags, unsigned *abort_word, unsigned epoch, int lane, int t, int txi,
+                                        int tyi, int ntx, int nty, unsigned spin_limit, bool all)
+{
+    const int ntiles = ntx * nty;
+    const int d = lane < 4 ? lane : lane + 1;                     // 0..8 without the centre
+    const int ax = txi + d % 3 - 1, ay = tyi + d / 3 - 1;
+    const bool has = lane < 8 && ax >= 0 && ax < ntx && ay >= 0 && ay < nty;
+    const unsigned *pw = (lane == 8) ? abort_word : flags + (size_t)(has ? ay * ntx + ax : t) * kFlagStride;
+    for (unsigned spins = 0;; ++spins) {
+        bool behind = false, aborted = false;
+        if (!all) {
+            unsigned v = 0;
+            if (lane < 9) v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            behind = !(kWhatIf & 16) && has && (int)(v - epoch) < 0;
+            aborted = lane == 8 && v != 0u;
+        } else {                                                  // host: ntiles <= 256; the four loads of a lane go out together
+            unsigned v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = lane + 64 * j;
+                v[j] = __hip_atomic_load(flags + (size_t)(q < ntiles ? q : t) * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const unsigned ab = lane == 0 ? __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            int lag = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lag |= (int)(v[j] - epoch);   // negative if any of them is behind
+            behind = lag < 0;
+            aborted = ab != 0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(aborted) != 0ull) return true;
+        if (__builtin_amdgcn_ballot_w64(behind) == 0ull) return false;
+        if (spins >= spin_limit) {
+            if (lane == 0) __hip_atomic_store(abort_word, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+template <int R, int NW, int BORDER>
+__device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, int txi, int tyi,
+                                                  float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
+                                                  float (*s_x22)[kTileW], unsigned (*s_err)[kTileW], int *s_ctl)
+{
+    static_assert(R >= 2 && R <= 4, "a thread's rows travel as one 16-byte vector");
+    const int nx = a.nx, ny = a.ny, ntx = a.ntx, nty = a.nty;
+    const int ntiles = ntx * nty;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const PxGeom g = px_geometry<R, NW>(a, t, txi, tyi, lane, wv);
+    const int gx = g.gx, gy0 = g.gy0;
+    const bool wave_live = g.wave_live, halo = g.halo, ring = g.ring;
+    const unsigned plane_stride = g.plane_stride, parity_stride = g.parity_stride, pub_off = g.pub_off, src_off = g.src_off;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xslab, 0, a.xslab_bytes, 0x00020000);
+    unsigned *abort_word = a.flags + (size_t)ntiles * kFlagStride;
+    const float *I0 = a.base + (size_t)P_I0 * a.plane_elems;
+    const float *I1 = a.base + (size_t)P_I1 * a.plane_elems;
+    const float *I1x = a.base + (size_t)P_I1X * a.plane_elems;
+    const float *I1y = a.base + (size_t)P_I1Y * a.plane_elems;
+
+    TileState<R> s;
+    px_load_owned<R>(s, a, g);
     for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;
 
     unsigned epoch = 0;
@@ -141,31 +327,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
         const bool stamp = a.stamps && w == a.stamp_warp && threadIdx.x == 0;
         unsigned long long *st = a.stamps + (size_t)t * kPersistStamps;
         if (stamp) { st[0] = __builtin_amdgcn_s_memrealtime(); st[13] = __builtin_amdgcn_s_memtime(); }
-        // ---- the warp constants of the owned pixels (src/global_faldoi.cpp:635-657; tvl1_warp_kernel) ----
-        // (dealing the owned pixels to all threads through LDS, two pixels each instead of R for the owners and none for the
-        // halo, was measured: no faster -- the phase is bound by its ~530 vector instructions per pixel, not by their spread)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float rc = 0.0f, wx = 0.0f, wy = 0.0f;               // the halo's constants arrive with the exchange
-            if (!(kWhatIf & 32) && s.own[r]) {
-                const int gy = gy0 + r;
-                float i0v = I0[gy * nx + gx];
-                asm volatile("" : "+v"(i0v));
-                const float uu = (float)gx + s.u1[r];            // src/bicubic_interpolation.c:259-260
-                const float vv = (float)gy + s.u2[r];
-                const BicubicTaps tp = bicubic_taps(uu, vv, nx, ny);
-                float w0 = 0.0f;                                 // border_out = true (:635-637)
-                if (!tp.clamped) {
-                    w0 = bicubic_eval_rows(I1, tp, nx);
-                    wx = bicubic_eval_rows(I1x, tp, nx);
-                    wy = bicubic_eval_rows(I1y, tp, nx);
-                }
-                rc = rho_const(w0, wx, wy, s.u1[r], s.u2[r], i0v);
-            }
-            s.rc[r] = rc;
-            s.ix[r] = wx;
-            s.iy[r] = wy;
-        }
+        px_warp_constants<R>(s, I0, I1, I1x, I1y, gx, gy0, nx, ny);
         if (stamp) {
             float sink = s.rc[0] + s.rc[R - 1] + s.iy[R - 1];
             asm volatile("" : "+v"(sink));
@@ -179,24 +341,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             ++epoch;
             const unsigned par = (epoch & 1u) * parity_stride;
 
-            // ---- publish: write-through, one 16-byte vector (the thread's R rows) per plane ----
-            if (ring) {
-                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u1), rsrc, par + pub_off + 0u * plane_stride, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u2), rsrc, par + pub_off + 1u * plane_stride, 0, 16);
-                if (!first) {                                     // at the start of a warp ubar = u (:659-660)
-                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub1), rsrc, par + pub_off + 2u * plane_stride, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub2), rsrc, par + pub_off + 3u * plane_stride, 0, 16);
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x11), rsrc, par + pub_off + 4u * plane_stride, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x12), rsrc, par + pub_off + 5u * plane_stride, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x21), rsrc, par + pub_off + 6u * plane_stride, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x22), rsrc, par + pub_off + 7u * plane_stride, 0, 16);
-                if (first) {
-                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.rc), rsrc, par + pub_off + 8u * plane_stride, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ix), rsrc, par + pub_off + 9u * plane_stride, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.iy), rsrc, par + pub_off + 10u * plane_stride, 0, 16);
-                }
-            }
+            if (ring) px_publish<R>(s, rsrc, par + pub_off, plane_stride, first);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the barrier
             if (a.stamps && w == a.stamp_warp && threadIdx.x == 64 * (NW / 2)) st[first ? 7 : 12] = __builtin_amdgcn_s_memrealtime();
             __syncthreads();
@@ -205,27 +350,8 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
                 if (stamp) st[first ? 2 : 8] = __builtin_amdgcn_s_memrealtime();
             }
 
-            // ---- wait for the neighbours' epoch (one wave: lanes 0..7 one neighbour each, lane 8 the abort word) ----
-            if (wv == 0) {
-                const int d = lane < 4 ? lane : lane + 1;         // 0..8 without the centre
-                const int ax = txi + d % 3 - 1, ay = tyi + d / 3 - 1;
-                const bool has = lane < 8 && ax >= 0 && ax < ntx && ay >= 0 && ay < nty;
-                const unsigned *pw = (lane == 8) ? abort_word : a.flags + (size_t)(has ? ay * ntx + ax : t) * kFlagStride;
-                bool failed = false;
-                for (unsigned spins = 0;; ++spins) {
-                    unsigned v = 0;
-                    if (lane < 9) v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool behind = !(kWhatIf & 16) && has && (int)(v - epoch) < 0;
-                    const bool aborted = lane == 8 && v != 0u;
-                    if (__builtin_amdgcn_ballot_w64(aborted) != 0ull) { failed = true; break; }
-                    if (__builtin_amdgcn_ballot_w64(behind) == 0ull) break;
-                    if (spins >= a.spin_limit) {
-                        if (lane == 0) __hip_atomic_store(abort_word, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        failed = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
+            if (wv == 0) {                                        // one wave waits for the neighbours' epoch
+                const bool failed = px_wait(a.flags, abort_word, epoch, lane, t, txi, tyi, ntx, nty, a.spin_limit, false);
                 if (lane == 0) s_ctl[0] = failed ? 1 : 0;
             }
             __syncthreads();
@@ -233,49 +359,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the loads below the poll
             if (stamp) st[first ? 3 : 9] = __builtin_amdgcn_s_memrealtime();
 
-            // ---- fetch the halo from its owners' slabs (sc1 loads only) ----
-            {
-                xvec4 q[kXPlanes];
-#pragma unroll
-                for (int k = 0; k < kXPlanes; ++k) q[k] = xvec4{ 0u, 0u, 0u, 0u };
-                if (halo) {
-                    q[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 0u * plane_stride, 0, 16);
-                    q[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 1u * plane_stride, 0, 16);
-                    if (!first) {
-                        q[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 2u * plane_stride, 0, 16);
-                        q[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 3u * plane_stride, 0, 16);
-                    }
-                    q[4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 4u * plane_stride, 0, 16);
-                    q[5] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 5u * plane_stride, 0, 16);
-                    q[6] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 6u * plane_stride, 0, 16);
-                    q[7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 7u * plane_stride, 0, 16);
-                    if (first) {
-                        q[8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 8u * plane_stride, 0, 16);
-                        q[9] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 9u * plane_stride, 0, 16);
-                        q[10] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, par + src_off + 10u * plane_stride, 0, 16);
-                    }
-                }
-                unpack_rows<R>(s.u1, q[0], halo);
-                unpack_rows<R>(s.u2, q[1], halo);
-                unpack_rows<R>(s.ub1, q[2], halo && !first);
-                unpack_rows<R>(s.ub2, q[3], halo && !first);
-                unpack_rows<R>(s.x11, q[4], halo);
-                unpack_rows<R>(s.x12, q[5], halo);
-                unpack_rows<R>(s.x21, q[6], halo);
-                unpack_rows<R>(s.x22, q[7], halo);
-                unpack_rows<R>(s.rc, q[8], halo && first);
-                unpack_rows<R>(s.ix, q[9], halo && first);
-                unpack_rows<R>(s.iy, q[10], halo && first);
-            }
-            if (first) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    s.ub1[r] = s.u1[r];                            // start of a warp: ubar = u (:659-660)
-                    s.ub2[r] = s.u2[r];
-                    s.gr[r] = grad_sq(s.ix[r], s.iy[r]);           // :648-652
-                    s.rgr[r] = recip_f64(s.gr[r]);
-                }
-            }
+            px_fetch<R>(s, rsrc, par + src_off, plane_stride, halo, first);
             if (stamp) {
                 float sink = s.u1[0] + s.x22[R - 1] + s.iy[R - 1];
                 asm volatile("" : "+v"(sink));
@@ -298,19 +382,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
         if (stamp) { st[6] = __builtin_amdgcn_s_memrealtime(); st[14] = __builtin_amdgcn_s_memtime(); }
     }
 
-    // ---- the solved state of the owned pixels (ubar is dead after the last warp) ----
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (s.own[r]) {
-            const int p = (gy0 + r) * nx + gx;
-            dst[0 * a.plane_elems + p] = s.u1[r];
-            dst[1 * a.plane_elems + p] = s.u2[r];
-            dst[4 * a.plane_elems + p] = s.x11[r];
-            dst[5 * a.plane_elems + p] = s.x12[r];
-            dst[6 * a.plane_elems + p] = s.x21[r];
-            dst[7 * a.plane_elems + p] = s.x22[r];
-        }
-    }
+    px_store_owned<R>(s, a, g);
 }
 
 template <int R, int NW>

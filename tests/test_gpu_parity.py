@@ -180,6 +180,37 @@ def test_persistent_kernel_equals_per_launch_path_and_checker(ctx, oracle, monke
         assert list(got[2]) == list(oit) and bits_equal(got[3], oerr)
 
 
+@pytest.mark.parametrize("w,h,warps,inner,tol,chunk", [(300, 200, 4, 60, 0.05, 0), (1024, 436, 3, 45, 0.05, 0), (640, 360, 3, 80, 0.03, 0),
+                                                      (192, 128, 5, 400, 0.01, 0), (257, 131, 3, 33, 0.05, 3), (257, 131, 3, 120, 0.02, 0),
+                                                      (70, 3, 2, 20, 0.01, 7)])
+def test_persistent_kernel_with_the_tolerance_stop(ctx, oracle, monkeypatch, w, h, warps, inner, tol, chunk):
+    # the reference's stop test (max |du|^2 <= tol^2 over the whole image) decided by the resident tiles themselves, every chunk:
+    # same iteration counts, errors, flow and duals as the launch-per-chunk path with its control kernel, and as the CPU checker;
+    # stops in the middle of a chunk (exact-length re-run from the LDS snapshot), at its end, and never (iteration bound)
+    i0n, i1n, gt = synthetic_pair(w, h, seed=w * 3 + h, amp=2.0)
+    u0 = (0.7 * gt).astype(np.float32)
+    ou, oit, oerr, oxi = oracle.tvl1_global(i0n, i1n, u0, lam=40.0, theta=0.3, tau=0.125, tol=tol, warps=warps, max_inner=inner,
+                                            tol_stop=True)
+    out = {}
+    for persist in ("0", "1"):
+        monkeypatch.setenv("FALDOI_PERSIST", persist)
+        b = F.Tvl1Batch(ctx, 1, w, h)
+        try:
+            b.upload(0, i0n, i1n, u0)
+            its, errs, _, launches = b.solve(warps=warps, max_inner=inner, tol=tol, chunk=chunk)
+            u, xi = b.download(0, want_xi=True)
+            out[persist] = (u, xi, its[0].copy(), errs[0].copy(), b.last_persistent())
+        finally:
+            b.close()
+    assert not out["0"][4] and out["1"][4], "the persistent path was not taken"
+    for got in out.values():
+        assert list(got[2]) == list(oit), (got[2], oit)
+        assert bits_equal(got[0], ou), mismatch_report(got[0], ou)
+        assert bits_equal(got[1], oxi) and bits_equal(got[3], oerr)
+    # (the cases stop after 24 6 5 5 | 23 9 6 | 80 32 14 | 285 73 56 55 55 | 24 8 5 | 120 89 14 | 20 20 iterations: inside a chunk
+    #  of five, on its last iteration, and at the iteration bound)
+
+
 def test_persistent_kernel_gives_up_cleanly_and_the_per_launch_path_takes_over(ctx, monkeypatch, capfd):
     # every spin in the persistent kernel is bounded; with the bound set to one poll some tile gives up in the first exchange,
     # raises the abort word, all workgroups leave, and the solve is redone on the per-launch path: same result, no hang
