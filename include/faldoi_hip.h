@@ -129,9 +129,9 @@ int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *c
 /* Launch schedule the last batch_solve chose: tile = 64 columns x rows_per_thread*waves rows, `chunk` inner
  * iterations per launch of the fused kernel (reporting only; results do not depend on it). */
 int faldoi_tvl1_batch_last_schedule(faldoi_tvl1_batch *b, int *rows_per_thread, int *waves, int *chunk);
-/* *persistent = 1 when the last batch_solve ran as ONE launch of the persistent kernel (a static schedule, tol_stop == 0, of
- * one pair whose tiles fit the chip one per compute unit: every tile's state stays in registers for the whole solve and only
- * the halo is exchanged between workgroups); chunk_launches is then 1, `chunk` the iterations between two exchanges and
+/* *persistent = 1 when the last batch_solve ran as ONE launch of the persistent kernel (one pair whose tiles fit the chip one
+ * per compute unit: every tile's state stays in registers for the whole solve and only the halo is exchanged between
+ * workgroups; with tol_stop != 0 the workgroups also take the reference's stop decision themselves, every `chunk` iterations); chunk_launches is then 1, `chunk` the iterations between two exchanges and
  * chunk_kernel_ms that launch's duration.  The environment variable FALDOI_PERSIST=0 selects the per-launch path; results are
  * identical on both. */
 int faldoi_tvl1_batch_last_persistent(faldoi_tvl1_batch *b, int *persistent);

@@ -414,6 +414,9 @@ def case_persist(rng):
                lambda_=float(rng.choice([40.0, 10.0, 0.5, 120.0])), theta=float(rng.choice([0.3, 0.1, 0.8])),
                tau=float(rng.choice([0.125, 0.25, 0.05])), chunk=int(rng.choice([0, 0, 0, 1, 2, 3, 4, 6, 8])))
     cfg = str(rng.choice(["", "", "3,16,5", "4,13,5", "4,11,4", "4,16,8", "3,14,3", "3,16,2", "4,16,4"]))
+    if rng.random() < 0.5:                            # the tolerance stop, decided by the resident tiles (64x48 tiles only)
+        prm.update(tol_stop=1, tol=float(rng.choice([0.3, 0.1, 0.03, 0.01, 0.001])), max_inner=int(rng.integers(1, 90)))
+        cfg = str(rng.choice(["", "", "3,16,5", "3,16,2", "3,16,7", "3,16,4"]))
     res = []
     for persist in ("0", "1"):
         os.environ["FALDOI_PERSIST"] = persist
@@ -434,7 +437,7 @@ def case_persist(rng):
     r, n = res
     ok = same_up_to_nan_payload(r[0], n[0]) and same_up_to_nan_payload(r[1], n[1]) and np.array_equal(r[2], n[2]) and \
         same_up_to_nan_payload(r[3], n[3]) and not r[5]
-    desc = "%dx%d cfg=%r persistent=%s launches %d->%d %s xi=%s" % (w, h, cfg, n[5], r[4], n[4], prm, xi is not None)
+    desc = "%dx%d cfg=%r persistent=%s launches %d->%d iters %s %s xi=%s" % (w, h, cfg, n[5], r[4], n[4], list(n[2][0]), prm, xi is not None)
     return ok, desc
 
 
