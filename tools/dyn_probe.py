@@ -1,3 +1,5 @@
+"""Development aid: the reference-default solve (5 warps, tolerance stop) of the example pair on the launch-per-chunk path and on
+the persistent kernel with the stop test inside -- time of both, and that counts, errors and flow are identical."""
 import os, sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
