@@ -389,8 +389,9 @@ static hipError_t launch_persist_dyn(const PersistCfg &pc, dim3 grid, hipStream_
 {
     if (pc.R != 3 || pc.NW != 16) return hipErrorInvalidValue;
     const size_t lds = 8ull * 3 * 64 * 16 * sizeof(float);             // the snapshot: 96 KB beside 21 KB static (160 KB per CU)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&tvl1_persist_dyn_kernel<3, 16>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // per device, so not cached in a static: a process may hold contexts on several devices
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&tvl1_persist_dyn_kernel<3, 16>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((tvl1_persist_dyn_kernel<3, 16>), grid, dim3(64 * 16), lds, s, a);
     return hipGetLastError();
