@@ -21,7 +21,7 @@ EXPORTS = [
     "faldoi_ctx_synchronize", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
     "faldoi_tvl1_batch_create", "faldoi_tvl1_batch_destroy", "faldoi_tvl1_batch_upload",
     "faldoi_tvl1_batch_reset", "faldoi_tvl1_batch_solve", "faldoi_tvl1_batch_download",
-    "faldoi_tvl1_batch_last_timing", "faldoi_tvl1_batch_last_schedule", "faldoi_tvl1_batch_last_persistent", "faldoi_centered_gradient", "faldoi_forward_gradient",
+    "faldoi_tvl1_batch_last_timing", "faldoi_tvl1_batch_last_schedule", "faldoi_tvl1_batch_last_persistent", "faldoi_tvl1_schedule_query", "faldoi_centered_gradient", "faldoi_forward_gradient",
     "faldoi_divergence", "faldoi_bicubic_warp", "faldoi_selftest_division",
     "faldoi_preprocess_global", "faldoi_tvl1_batch_upload_images",
     "faldoi_nltvcsad_default_params", "faldoi_nltvcsad_global", "faldoi_image_to_lab",
@@ -114,6 +114,7 @@ def lib():
                                                 C.POINTER(C.c_long), C.POINTER(C.c_double)]
     L.faldoi_tvl1_batch_last_schedule.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.faldoi_tvl1_batch_last_persistent.argtypes = [vp, C.POINTER(C.c_int)]
+    L.faldoi_tvl1_schedule_query.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Tvl1Params), C.c_int] + [C.POINTER(C.c_int)] * 5
     L.faldoi_centered_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_forward_gradient.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
     L.faldoi_divergence.argtypes = [vp, _F, _F, _F, C.c_int, C.c_int]
@@ -472,6 +473,14 @@ class Tvl1Batch:
         xi = np.empty((4, self.h, self.w), np.float32) if want_xi else None
         _check(lib().faldoi_tvl1_batch_download(self._h, int(pair), u, _ptr(xi)))
         return (u, xi) if want_xi else u
+
+
+def schedule_query(npairs, w, h, compute_units=256, **params):
+    """(persistent, rows per thread, waves, iterations per launch or exchange, workgroups) batch_solve would choose (host logic)."""
+    p = default_params(**params)
+    o = [C.c_int() for _ in range(5)]
+    _check(lib().faldoi_tvl1_schedule_query(int(npairs), int(w), int(h), C.byref(p), int(compute_units), *[C.byref(v) for v in o]))
+    return (bool(o[0].value),) + tuple(v.value for v in o[1:])
 
 
 def queue_replay(ops, sims):

@@ -869,6 +869,35 @@ extern "C" int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve
     return FALDOI_OK;
 }
 
+extern "C" int faldoi_tvl1_schedule_query(int npairs, int nx, int ny, const faldoi_tvl1_params *prm, int compute_units,
+                                          int *persistent, int *rows_per_thread, int *waves, int *chunk, int *tiles)
+{
+    return abi_guard("the schedule query", [&] {
+        if (!prm) return fail(FALDOI_ERR_INVALID, "params is NULL");
+        if (npairs < 1 || nx < 2 || ny < 2 || compute_units < 1) return fail(FALDOI_ERR_INVALID, "npairs, size and compute units must be positive");
+        faldoi_ctx c;                                   // host-only stand-ins: the choice depends on sizes and the CU count alone
+        c.n_cu = compute_units;
+        faldoi_tvl1_batch b;
+        b.ctx = &c;
+        b.npairs = npairs;
+        b.nx = nx;
+        b.ny = ny;
+        TileCfg tc;
+        int k = 0;
+        pick_schedule(&b, prm, &tc, &k);
+        PersistCfg pc{ 0, 0, 0, 0 };
+        const bool persist = pick_persist(&b, prm, &pc);
+        if (persist) { tc = TileCfg{ pc.R, pc.NW }; k = pc.k; }
+        const int Sx = kTileW - 2 * k, Sy = tc.R * tc.NW - 2 * (persist ? pc.hy : k);
+        if (persistent) *persistent = persist ? 1 : 0;
+        if (rows_per_thread) *rows_per_thread = tc.R;
+        if (waves) *waves = tc.NW;
+        if (chunk) *chunk = k;
+        if (tiles) *tiles = ((nx + Sx - 1) / Sx) * ((ny + Sy - 1) / Sy) * npairs;
+        return (int)FALDOI_OK;
+    });
+}
+
 extern "C" int faldoi_tvl1_batch_last_persistent(faldoi_tvl1_batch *b, int *persistent)
 {
     if (!b || !persistent) return fail(FALDOI_ERR_INVALID, "NULL argument");

@@ -129,6 +129,12 @@ int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *c
 /* Launch schedule the last batch_solve chose: tile = 64 columns x rows_per_thread*waves rows, `chunk` inner
  * iterations per launch of the fused kernel (reporting only; results do not depend on it). */
 int faldoi_tvl1_batch_last_schedule(faldoi_tvl1_batch *b, int *rows_per_thread, int *waves, int *chunk);
+/* The schedule batch_solve chooses for `npairs` pairs of nx x ny with these parameters on a device with `compute_units`
+ * compute units: tile = 64 columns x rows_per_thread*waves rows, `chunk` iterations per launch (or, *persistent = 1, between
+ * two halo exchanges of the one persistent launch), `tiles` workgroups.  Host logic only -- no device is touched, so it also
+ * answers in a CPU-only build container; results never depend on the schedule.  Any out pointer may be NULL. */
+int faldoi_tvl1_schedule_query(int npairs, int nx, int ny, const faldoi_tvl1_params *prm, int compute_units,
+                               int *persistent, int *rows_per_thread, int *waves, int *chunk, int *tiles);
 /* *persistent = 1 when the last batch_solve ran as ONE launch of the persistent kernel (one pair whose tiles fit the chip one
  * per compute unit: every tile's state stays in registers for the whole solve and only the halo is exchanged between
  * workgroups; with tol_stop != 0 the workgroups also take the reference's stop decision themselves, every `chunk` iterations); chunk_launches is then 1, `chunk` the iterations between two exchanges and

@@ -24,6 +24,26 @@ def test_library_builds_and_exports_header_symbols():
     assert L.faldoi_abi_version() == 1
 
 
+def test_schedule_selection_is_host_logic_and_picks_what_was_measured(monkeypatch):
+    # which kernel path a solve takes depends on sizes and the CU count alone (faldoi_tvl1_schedule_query touches no device):
+    # one pair that fits the chip -> ONE persistent launch, 64x48 tiles, 5 iterations between halo exchanges (both stop modes);
+    # batches and frames with more tiles than CUs -> a launch per 5 iterations of 64x32 tiles; FALDOI_PERSIST=0 -> per launch
+    monkeypatch.delenv("FALDOI_PERSIST", raising=False)
+    monkeypatch.delenv("FALDOI_PERSIST_CFG", raising=False)
+    monkeypatch.delenv("FALDOI_TILE", raising=False)
+    q = F.capi.schedule_query
+    assert q(1, 1024, 436, warps=300, max_inner=10, tol_stop=0) == (True, 3, 16, 5, 247)       # BASELINE configs[1]
+    assert q(1, 1024, 436) == (True, 3, 16, 5, 247)                                              # the reference's defaults
+    assert q(1, 1024, 436, compute_units=128, tol_stop=0) == (False, 4, 8, 5, 380)               # does not fit half a chip
+    assert q(4, 1024, 436, tol_stop=0) == (False, 4, 8, 5, 4 * 380)                              # BASELINE configs[3] shape
+    assert q(1, 1920, 1080, tol_stop=0)[:4] == (False, 4, 8, 5)                                  # more tiles than CUs
+    assert q(1, 256, 192, tol_stop=0) == (True, 3, 16, 5, 5 * 6)
+    assert q(1, 1024, 436, max_inner=3, tol_stop=0) == (True, 3, 16, 3, 18 * 11)                 # chunk = the iteration bound
+    assert q(1, 1024, 436, chunk=16) == (False, 4, 16, 16, 32 * 14)                              # an explicit chunk the tiles cannot host
+    monkeypatch.setenv("FALDOI_PERSIST", "0")
+    assert q(1, 1024, 436, warps=300, max_inner=10, tol_stop=0) == (False, 4, 16, 10, 240)
+
+
 def test_default_params_are_the_reference_constants():
     p = F.default_params()
     # src/parameters.h:20-22,31,43,51
