@@ -211,11 +211,23 @@ def test_persistent_kernel_with_the_tolerance_stop(ctx, oracle, monkeypatch, w, 
     #  of five, on its last iteration, and at the iteration bound)
 
 
-def test_persistent_kernel_gives_up_cleanly_and_the_per_launch_path_takes_over(ctx, monkeypatch, capfd):
+@pytest.mark.parametrize("tol_stop", [0, 1])
+def test_persistent_kernel_gives_up_cleanly_and_the_per_launch_path_takes_over(ctx, monkeypatch, capfd, tol_stop):
     # every spin in the persistent kernel is bounded; with the bound set to one poll some tile gives up in the first exchange,
     # raises the abort word, all workgroups leave, and the solve is redone on the per-launch path: same result, no hang
+    # (both forms of the kernel: static schedule, tolerance stop)
     i0n, i1n, gt = synthetic_pair(640, 360, seed=3)
     z = np.zeros_like(gt)
+
+    def _static_solve(ctx, i0n, i1n, u0, xi0, **prm):
+        b = F.Tvl1Batch(ctx, 1, 640, 360)
+        try:
+            b.upload(0, i0n, i1n, u0, xi0)
+            its, errs, _, launches = b.solve(tol_stop=tol_stop, tol=0.05, **prm)
+            u, xi = b.download(0, want_xi=True)
+            return u, xi, its[0].copy(), errs[0].copy(), launches, b.last_persistent(), b.last_schedule()
+        finally:
+            b.close()
     monkeypatch.setenv("FALDOI_PERSIST", "0")
     ref = _static_solve(ctx, i0n, i1n, z, None, warps=3, max_inner=10)
     monkeypatch.setenv("FALDOI_PERSIST", "1")
