@@ -236,7 +236,8 @@ def test_persistent_kernel_gives_up_cleanly_and_the_per_launch_path_takes_over(c
     assert bits_equal(ref[0], new[0]) and bits_equal(ref[1], new[1]) and bits_equal(ref[3], new[3])
     if not new[5]:                                   # (all neighbours ready at the first poll is possible, just unlikely)
         assert new[4] == ref[4]
-        assert "per-launch path" in capfd.readouterr().err
+        if tol_stop == 0:                            # the note is printed once per process
+            assert "per-launch path" in capfd.readouterr().err
 
 
 def test_tvl1_nonzero_duals_and_parameters(ctx, oracle):
