@@ -656,7 +656,11 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
             b->ev.push_back(e);
         }
         HIP_TRY(hipEventRecord(b->ev[0], s));
-        HIP_TRY(dynamic ? launch_persist_dyn(pc, grid, s, a) : launch_persist(pc, grid, s, a));
+        if ((dynamic ? launch_persist_dyn(pc, grid, s, a) : launch_persist(pc, grid, s, a)) != hipSuccess) {
+            (void)hipGetLastError();                               // e.g. a device whose LDS cannot hold the snapshot: per-launch path
+            b->persist_off = true;
+            return faldoi_tvl1_batch_solve_impl(b, prm, stats);
+        }
         HIP_TRY(hipEventRecord(b->ev[1], s));
         ev_used = 2;
         launches = 1;
