@@ -19,6 +19,8 @@ __global__ void k(float *out, float seed, double dseed)
 #pragma unroll
     for (int i = 0; i < UNR; ++i) { a[i] = seed + i + threadIdx.x; p[i] = f2{a[i], a[i] + 1}; d[i] = dseed + i; }
     const float b = seed * 0.5f, c = seed * 0.25f;
+    const bool sel = (threadIdx.x & 7) != 3;
+    const unsigned msk = (threadIdx.x & 7) != 3 ? 0xffffffffu : 0x7fffff00u, sgn = (threadIdx.x & 15) == 5 ? 0x80000000u : 0u;
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int i = 0; i < UNR; ++i) {
@@ -48,6 +50,12 @@ __global__ void k(float *out, float seed, double dseed)
             if (OP == 23) a[i] = (float)__builtin_amdgcn_frexp_expf(a[i]) + b;  // frexp_exp + cvt + add (3 ops)
             if (OP == 24) a[i] = (float)((double)a[i]);                        // cvt + cvt (2 ops)
             if (OP == 26) a[i] = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a[i]), 0x8000) ? a[i] : b;       // ds_swizzle
+            if (OP == 27) a[i] = sel ? a[i] + b : a[i];                        // add + cndmask on a loop-invariant lane mask (2 ops)
+            if (OP == 28) a[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a[i] + b) & msk);   // add + v_and_b32 (2 ops)
+            if (OP == 29) a[i] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a[i] + b) & msk) | sgn);   // add + v_and_or_b32 (2 ops)
+            if (OP == 30) a[i] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a[i]) << 1) - 1u);         // v_lshl_add_u32
+            if (OP == 31) { const unsigned x = __builtin_bit_cast(unsigned, a[i]); a[i] = __builtin_bit_cast(float, x < msk ? x : msk); }   // v_min_u32
+            if (OP == 32) a[i] = __builtin_amdgcn_ballot_w64(a[i] > b) ? a[i] + c : a[i] + b;   // cmp + ballot + scalar select of the addend + add
         }
     }
     float s = 0;
@@ -106,5 +114,11 @@ int main()
     run<22>("v_sub_f32_dpp row_shl:1", 1, out);
     run<23>("frexp_exp+cvt+add (3 ops)", 1, out);
     run<24>("cvt f32->f64->f32 (2 ops)", 1, out);
+    run<27>("add + cndmask, invariant mask (2 ops)", 1, out);
+    run<28>("add + v_and_b32 (2 ops)", 1, out);
+    run<29>("add + v_and_or_b32 (2 ops)", 1, out);
+    run<30>("v_lshl_add_u32", 1, out);
+    run<31>("v_min_u32", 1, out);
+    run<32>("cmp + ballot + s_cselect + add", 1, out);
     return 0;
 }
