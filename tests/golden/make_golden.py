@@ -1,4 +1,4 @@
-"""Regenerates tests/golden/ref_primitives.npz from the REFERENCE's own compiled primitives.
+"""Regenerates tests/golden/ref_primitives.npz and tests/golden/ref_models.npz from the REFERENCE's own compiled objects.
 
 Run in the build container only (needs /root/reference and `make -C oracle ref`):
     python tests/golden/make_golden.py
@@ -125,5 +125,50 @@ def main():
     print("wrote ref_primitives.npz with", len(out), "arrays")
 
 
+def partition_case(P, rng_seed, w, h):
+    """The same seeded candidate pushes (heavy ties) into a Parts object, then the image -> partitions transfer."""
+    rng = np.random.default_rng(rng_seed)
+    for d in (0, 1):
+        for _ in range(300):
+            i, j = int(rng.integers(0, w)), int(rng.integers(0, h))
+            sim = float(rng.integers(0, 6)) * 0.25
+            u, v = float(rng.standard_normal()), float(rng.standard_normal())
+            P.push(d, i, j, u, v, sim)
+    P.transfer(True)
+
+
+def models():
+    """tests/golden/ref_models.npz: prepare_stuff + of_estimation of the reference AS CALLED for every functional (-m 0..7) on
+    a crop of the example pair, the Lab image, and the partition split of a candidate queue (tests/models_replay.py)."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import models_replay as MR
+    from util import sintel_pair
+    R = O.ref()
+    if R is None or not hasattr(R, "ref_op_create"):
+        raise SystemExit("oracle/_ref without the model objects: run `make -C oracle ref` first")
+    i0, i1 = sintel_pair(crop=MR.CROP)
+    out = {"crop": np.array(MR.CROP, np.int32)}
+    for method in range(8):
+        for k, v in MR.replay_reference(O, method, i0, i1).items():
+            out["m%d_%s" % (method, k)] = v
+    lab = np.empty_like(i0)
+    R.ref_rgb_to_lab(i0, i0.shape[1] * i0.shape[2], lab)
+    out["lab"] = lab
+    # partitions: geometry of three grids on an odd-sized crop, and where every candidate of a queue with many ties goes
+    j0, j1 = sintel_pair(crop=(300, 100, 53, 37))
+    j0n, j1n = O.preprocess_local(j0, j1)
+    for cols, rows in ((3, 2), (2, 3), (4, 1)):
+        A = O.Parts("ref", j0, j1, j0n, j1n, cols, rows)
+        out["parts_%dx%d_geometry" % (cols, rows)] = np.array([A.geometry(p) for p in range(A.count())], np.int32)
+        partition_case(A, 77, 53, 37)
+        for p in range(A.count()):
+            for d in (0, 1):
+                out["parts_%dx%d_queue_%d_%d" % (cols, rows, p, d)] = A.drain(p, d)
+        out["parts_%dx%d_any_empty" % (cols, rows)] = np.array([int(A.any_empty())], np.int32)
+    np.savez_compressed(os.path.join(HERE, "ref_models.npz"), **out)
+    print("wrote ref_models.npz with", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "ref_models.npz")), "bytes")
+
+
 if __name__ == "__main__":
     main()
+    models()
