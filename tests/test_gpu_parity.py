@@ -1121,6 +1121,33 @@ def test_match_growing_other_functionals_bit_exact(ctx, oracle, method):
     assert bits_equal(got_ene, want_ene), mismatch_report(got_ene, want_ene)
 
 
+@pytest.mark.parametrize("method", [3, 4])
+def test_local_faldoi_cli_other_functionals(oracle, tmp_path, method):
+    """`local_faldoi -m 3` (NLTV-L1, weighted) and `-m 4` (TV-CSAD) through the executable: the argv and file surface of the
+    reference (`src/local_faldoi.cpp:1756-2110`), raw RGB frames in, `.flo` + energy map out, byte-identical to the CPU checker."""
+    from PIL import Image
+    bins = F.build.build_host()
+    crop = (400, 150, 48, 36)
+    i0, i1 = sintel_pair(crop)
+    h, w = i0.shape[1:]
+    for k, im in enumerate((i0, i1)):
+        Image.fromarray(im.transpose(1, 2, 0).astype(np.uint8), "RGB").save(tmp_path / ("f%d.png" % k))
+    (tmp_path / "ims.txt").write_text("%s\n%s\n" % (tmp_path / "f0.png", tmp_path / "f1.png"))
+    a, b = oracle.preprocess_local(i0, i1)
+    go, ba = _seed_flows(oracle, a, b, 0.02, seed=20 + method)
+    F.flo.write_flo(str(tmp_path / "s0.flo"), go)
+    F.flo.write_flo(str(tmp_path / "s1.flo"), ba)
+    r = subprocess.run([str(c) for c in (bins["local_faldoi"], tmp_path / "ims.txt", tmp_path / "s0.flo", tmp_path / "s1.flo",
+                                         tmp_path / "local.flo", tmp_path / "sim.tiff", "-m", method, "-wr", 5)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    want, want_ene, _ = oracle.local_faldoi_raw(i0, i1, go, ba, method)
+    got = F.flo.read_flo(str(tmp_path / "local.flo"))
+    assert bits_equal(got, want), mismatch_report(got, want)
+    sim = open(tmp_path / "sim.tiff").read().split()
+    assert np.array_equal(np.array([float.fromhex(v) for v in sim[4:]], np.float32), want_ene.ravel())
+
+
 def test_match_growing_other_functionals_argument_checks(ctx):
     i0, i1 = sintel_pair((400, 150, 40, 30))
     z = np.full((2, 30, 40), np.nan, np.float32)
