@@ -239,6 +239,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             guarded(out, "cpu_baseline", lambda: cpu_baseline_leg(out, F, np, batch, pairs))
         if world == 1 and data_kind != "synthetic" and not args.no_secondary:
+            guarded(out, "reference_defaults", lambda: reference_defaults_leg(out, batch))
             guarded(out, "nltvcsad", lambda: nltvcsad_leg(out, F, np, ctx, pairs, load_rgb_planar(f2)))
             guarded(out, "local_step", lambda: local_step_leg(out, args, F, np, ctx, load_rgb_planar(f2), load_rgb_planar(f3)))
         print(json.dumps(out), flush=True)
@@ -395,6 +396,32 @@ def cpu_baseline_leg(out, F, np, batch, pairs):
                                    "sample": "%d warps x %d iterations of the same pair (%.1f s)" % (WARPS // 10, INNER, cpu1_s)}
     out["epe_vs_cpu"] = {"mean_epe_px": epe, "bit_identical": bool(
         np.array_equal(gu.view(np.uint32), ou.view(np.uint32))), "gate": 1e-4}
+
+
+def reference_defaults_leg(out, batch):
+    """the same pair with the reference's own schedule -- 5 warps, up to 400 iterations each, the
+    tolerance stop (tol 0.01) on -- on the persistent kernel (the stop test decided by the resident tiles) and, for comparison,
+    with one launch per chunk and the control kernel between launches.  Leaves the batch holding the headline's result."""
+    res = {}
+    had = os.environ.get("FALDOI_PERSIST")
+    for name, env in (("persistent", None), ("per_launch", "0")):
+        if env is None:
+            os.environ.pop("FALDOI_PERSIST", None)
+        else:
+            os.environ["FALDOI_PERSIST"] = env
+        batch.solve()
+        runs = [batch.solve() for _ in range(3)]
+        its = runs[0][0]
+        ms = min(r[2] for r in runs)
+        res[name] = {"device_ms": round(ms, 3), "iterations_per_warp": [int(v) for v in its[0]], "launches": int(runs[0][3]),
+                     "Mpx_iter_per_s": round(W * H * float(its[0].sum()) / ms / 1e3, 1), "one_persistent_launch": bool(batch.last_persistent())}
+    if had is None:
+        os.environ.pop("FALDOI_PERSIST", None)
+    else:
+        os.environ["FALDOI_PERSIST"] = had
+    res["same_iteration_counts"] = res["persistent"]["iterations_per_warp"] == res["per_launch"]["iterations_per_warp"]
+    out.setdefault("secondary", {})["tvl1_reference_defaults_5_warps_tolerance_stop"] = res
+    batch.solve(warps=WARPS, max_inner=INNER, tol_stop=0)
 
 
 def nltvcsad_leg(out, F, np, ctx, pairs, rgb0):
