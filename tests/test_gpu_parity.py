@@ -211,6 +211,40 @@ def test_persistent_kernel_with_the_tolerance_stop(ctx, oracle, monkeypatch, w, 
     #  of five, on its last iteration, and at the iteration bound)
 
 
+def test_persistent_kernel_random_cases_equal_the_per_launch_path(ctx, monkeypatch):
+    # a bounded slice of tests/tools/fuzz_parity.py --family persist (which has run over 10 000 cases): random sizes up to the
+    # full frame, schedules, parameters, start flows and duals, both stop modes -- the two kernel paths must agree bit for bit
+    rng = np.random.default_rng(20261004)
+    took = 0
+    for case in range(36):
+        w, h = (int(rng.integers(2, 1100)), int(rng.integers(2, 480))) if case % 3 else (int(rng.integers(2, 200)), int(rng.integers(2, 140)))
+        i0n, i1n, gt = synthetic_pair(max(w, 4), max(h, 4), seed=int(rng.integers(1 << 30)), amp=float(rng.uniform(0, 8)))
+        i0n, i1n, gt = np.ascontiguousarray(i0n[:h, :w]), np.ascontiguousarray(i1n[:h, :w]), np.ascontiguousarray(gt[:, :h, :w])
+        u0 = (gt * float(rng.choice([0.0, 0.5, 1.0])) + rng.normal(0, float(rng.choice([0, 0.5, 20.0])), (2, h, w))).astype(np.float32)
+        xi = (rng.normal(0, 0.5, (4, h, w))).astype(np.float32) if rng.random() < 0.5 else None
+        prm = dict(warps=int(rng.integers(1, 5)), max_inner=int(rng.integers(1, 24)), tol_stop=0,
+                   lambda_=float(rng.choice([40.0, 10.0, 120.0])), theta=float(rng.choice([0.3, 0.1, 0.8])),
+                   tau=float(rng.choice([0.125, 0.25, 0.05])), chunk=int(rng.choice([0, 0, 0, 2, 3, 4])))
+        if case % 2:
+            prm.update(tol_stop=1, tol=float(rng.choice([0.3, 0.1, 0.03, 0.01])), max_inner=int(rng.integers(1, 70)))
+        res = []
+        for persist in ("0", "1"):
+            monkeypatch.setenv("FALDOI_PERSIST", persist)
+            b = F.Tvl1Batch(ctx, 1, w, h)
+            try:
+                b.upload(0, i0n, i1n, u0, xi)
+                its, errs, _, _ = b.solve(**prm)
+                u, x = b.download(0, want_xi=True)
+                res.append((u, x, its.copy(), errs.copy(), b.last_persistent()))
+            finally:
+                b.close()
+        r, n = res
+        assert not r[4]
+        took += int(n[4])
+        assert bits_equal(r[0], n[0]) and bits_equal(r[1], n[1]) and np.array_equal(r[2], n[2]) and bits_equal(r[3], n[3]), (case, w, h, prm)
+    assert took >= 30                                  # (an explicit chunk the tiles cannot host stays on the per-launch path)
+
+
 @pytest.mark.parametrize("tol_stop", [0, 1])
 def test_persistent_kernel_gives_up_cleanly_and_the_per_launch_path_takes_over(ctx, monkeypatch, capfd, tol_stop):
     # every spin in the persistent kernel is bounded; with the bound set to one poll some tile gives up in the first exchange,
