@@ -32,15 +32,40 @@ NLTV_BYTES_PER_PX_ITER = 4 * (75 + 48 + 82 + 4)
 VALU_PEAK_GINSTR = 1024 * 0.5 * 2.4   # 256 CUs x 4 SIMD-32 x one wave64 VALU instruction per 2 clk x 2.4 GHz (MI355X_MICROARCH.md)
 # rocprofv3 counter summaries of the kernels (per launch), written by tools/pmc_summary.py from the PMC passes
 # of the SAME bench command; nothing here is typed in by hand
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r03_counters.json")
+DRIFT_LIMIT = 0.05            # a stored counter is only used while the kernel still lasts what it lasted when it was profiled
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources (csrc/*.hip|hpp|inc, names and bytes): tools/pmc_summary.py stamps the counters file with
+    it, so instruction and byte counts of an older build are never multiplied by this build's durations."""
+    import hashlib
+    d = os.path.join(ROOT, "faldoi-ipol_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".inc")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def load_counters():
+    """The counters file, or {} when it is missing or belongs to other kernel sources (then every counter-derived field of
+    the line is null and `counters_stale` says why)."""
     try:
         with open(COUNTERS_JSON) as f:
-            return json.load(f)
+            cnt = json.load(f)
     except (OSError, ValueError):
         return {}
+    if cnt.get("_source_hash") != kernel_source_hash():
+        return {"_stale": "profiles counters were collected for kernel sources %s, this build is %s"
+                          % (cnt.get("_source_hash"), kernel_source_hash())}
+    return cnt
+
+
+def within_drift(live_us, stored_us):
+    return bool(live_us and stored_us and abs(live_us - stored_us) <= DRIFT_LIMIT * stored_us)
 
 
 def launcher_selftest(args, rank, world):
@@ -86,6 +111,13 @@ def launch_ranks(ngpus, argv):
     the HIP library is imported, so this process never touches a GPU (a process that has initialised the
     GPU must not be replaced or re-launched)."""
     import subprocess
+    preload = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    if "rocprof" in preload.lower():
+        # under rocprofv3 the preloaded tool library has initialised the GPU in THIS process already: starting the ranks from here
+        # would be a launcher hop, and the counters collected would not be a rank's
+        sys.stderr.write("bench.py: --gpus %d under a profiler: profile ONE rank instead (python3 bench.py --gpus N directly after "
+                         "`--`, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set)\n" % ngpus)
+        return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
@@ -188,6 +220,15 @@ def main():
     px_iters_local = float(args.steps) * npairs * W * H * WARPS * INNER
     dt_max, px_iters = F.shard.reduce_timing(dt, px_iters_local, dist if use_dist else None, dev)
     per_rank = F.shard.gather_scalars(px_iters_local / dt / 1e6, dist if use_dist else None, dev)
+    # Parity evidence of every rank's own result (outside the timed region; world > 1 only -- alone, rank 0's full comparison
+    # below covers it): a 48-bit checksum of the flow the timed steps left behind, and a bounded comparison with the CPU checker.
+    per_rank_check = None
+    if world > 1:
+        crc, same = rank_check(F, np, batch, pairs, step, args.no_cpu_baseline)
+        crcs = F.shard.gather_scalars(crc, dist, dev)
+        sames = F.shard.gather_scalars(same, dist, dev)
+        per_rank_check = [{"rank": r, "flow_sha256_48": "%012x" % int(c), "bit_identical_to_cpu_first_%d_warps" % CHECK_WARPS:
+                           (None if v < 0 else bool(v))} for r, (c, v) in enumerate(zip(crcs, sames))]
 
     # Kernel durations, outside the timed region, from HIP events on the library's own stream.
     #  * A static one-pair schedule runs as ONE launch of the persistent kernel (tvl1_persist_kernel.hpp); the library
@@ -236,9 +277,12 @@ def main():
         out = headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers, dev_ms, launches)
         sys.stderr.write("bench headline: %s\n" % json.dumps({k: out[k] for k in ("value", "unit", "n_gpus", "ms_per_step")}))
         sys.stderr.flush()
-        if world == 1 and not args.no_cpu_baseline:
+        if per_rank_check is not None:
+            out["per_rank_check"] = per_rank_check
+        if not args.no_cpu_baseline:              # rank 0, any world: the full step on the CPU checker beside the GPU's (~1.6 s)
             guarded(out, "cpu_baseline", lambda: cpu_baseline_leg(out, F, np, batch, pairs))
         if world == 1 and data_kind != "synthetic" and not args.no_secondary:
+            guarded(out, "batch_of_4", lambda: batch4_leg(out, args, F, np, ctx, pairs, synthetic_pair))
             guarded(out, "reference_defaults", lambda: reference_defaults_leg(out, batch))
             guarded(out, "nltvcsad", lambda: nltvcsad_leg(out, F, np, ctx, pairs, load_rgb_planar(f2)))
             guarded(out, "local_step", lambda: local_step_leg(out, args, F, np, ctx, load_rgb_planar(f2), load_rgb_planar(f3)))
@@ -248,6 +292,91 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+CHECK_WARPS = 30
+
+
+def rank_check(F, np, batch, pairs, step, skip_cpu):
+    """(48-bit sha256 prefix of pair 0's flow as the timed steps left it, 1 / 0 / -1 = the first CHECK_WARPS warps of the same
+    solve are / are not bit-identical to the CPU checker / not checked).  Leaves the batch holding the headline's result."""
+    import hashlib
+    crc = float(int(hashlib.sha256(F.flo.flo_bytes(batch.download(0))).hexdigest()[:12], 16))
+    if skip_cpu:
+        return crc, -1.0
+    from oracle import oracle as O            # checker only, after the timed region
+    i0n, i1n, u0 = pairs[0]
+    ou = O.tvl1_global(i0n, i1n, u0, warps=CHECK_WARPS, max_inner=INNER, tol_stop=False)[0]
+    batch.solve(warps=CHECK_WARPS, max_inner=INNER, tol_stop=0)
+    same = float(np.array_equal(batch.download(0).view(np.uint32), ou.view(np.uint32)))
+    step()
+    return crc, same
+
+
+def batch4_leg(out, args, F, np, ctx, pairs, synthetic_pair):
+    """BASELINE configs[3]'s per-GPU share inside the N = 1 line: 32 pairs on 8 GPUs = 4 pairs of 1024x436 per rank, the same
+    static schedule as the headline.  More tiles than CUs: the launch-per-chunk path (64x32 tiles of 512 threads, 5 iterations per
+    launch).  Kernel durations by the difference method of the headline's per-launch path; counters from the profile of this
+    very command (tools/profile_bench.sh), used only while sources and durations still match."""
+    n4 = 4
+    b = F.Tvl1Batch(ctx, n4, W, H)
+    try:
+        ps = [pairs[0]] + [synthetic_pair(W, H, seed=4321 + i, amp=4.0)[:2] + (np.zeros((2, H, W), np.float32),) for i in range(1, n4)]
+        for i, (i0n, i1n, u0) in enumerate(ps):
+            b.upload(i, i0n, i1n, u0)
+        prm = dict(warps=WARPS, max_inner=INNER, tol_stop=0)
+        b.solve(**prm)
+        steps = max(3, args.steps)
+        t0 = time.perf_counter()
+        dev_ms = [b.solve(**prm)[2] for _ in range(steps)]
+        wall = time.perf_counter() - t0
+        R, NW, K = b.last_schedule()
+        launches = b.last_timing()[1]
+
+        def best(env):
+            for k_, v_ in env.items():
+                os.environ[k_] = v_
+            t = min(b.solve(**prm)[2] for _ in range(3))
+            for k_ in env:
+                os.environ[k_] = "1"
+            return t
+        t1 = best({})
+        warp_us = max(0.0, (best({"FALDOI_WARP_REPEAT": "2"}) - t1) * 1e3 / WARPS)
+        chunk_us = max(0.0, (best({"FALDOI_CHUNK_REPEAT": "2"}) - t1) * 1e3 / launches)
+        cnt = load_counters()
+        ck, wk = cnt.get("tvl1_chunk_kernel@batch4", {}), cnt.get("tvl1_warp_kernel@batch4", {})
+        same = ck.get("tile") == [R, NW] and ck.get("chunk") == K and ck.get("pairs") == n4 and ck.get("size") == [W, H]
+        ok = same and within_drift(chunk_us - 1.5, ck.get("avg_us"))
+        valu, traffic = (ck.get("SQ_INSTS_VALU"), _traffic(ck)) if ok else (None, None)
+        px = n4 * W * H
+        it_per_launch = WARPS * INNER / float(launches)
+        leg = {"pairs_per_gpu": n4, "value": round(px * WARPS * INNER * steps / wall / 1e6, 1), "unit": "Mpx*iter/s",
+               "ms_per_step": round(wall / steps * 1e3, 3), "device_ms_per_step": round(min(dev_ms), 3), "steps": steps,
+               "kernel_path": "one launch per chunk of iterations", "persistent": bool(b.last_persistent()),
+               "kernel": "tvl1_chunk_kernel<%d,%d>" % (R, NW), "tile": "64x%d" % (R * NW), "iters_per_launch": K,
+               "launches_per_step": launches, "launch_us": round(chunk_us, 2), "launch_us_rocprof": ck.get("avg_us") if same else None,
+               "warp_kernel_us": round(warp_us, 2), "warp_kernel_us_rocprof": wk.get("avg_us"),
+               "counters_used": bool(ok),
+               "roofline": {"bound": "valu", "achieved": round(valu / (chunk_us * 1e-6) / 1e9, 1) if valu else None,
+                            "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+                            "frac": round(valu / (chunk_us * 1e-6) / 1e9 / VALU_PEAK_GINSTR, 4) if valu else None,
+                            "traffic": traffic,
+                            "valu_instr_per_useful_px_iter": round(valu * 64 / (px * it_per_launch), 1) if valu else None,
+                            "owned_over_computed_px": round((64 - 2 * K) * (R * NW - 2 * K) / float(64 * R * NW), 3)},
+               "hbm": {"algorithmic_bytes_per_launch": int(px * BYTES_PER_PX_ITER * it_per_launch),
+                       "effective_GBps": round(px * BYTES_PER_PX_ITER * it_per_launch / (chunk_us * 1e-6) / 1e9, 1) if chunk_us > 0 else None,
+                       "measured_frac": round(traffic / (chunk_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                       "warp_kernel_measured_traffic": _traffic(wk) if ok else None}}
+        if not args.no_cpu_baseline:          # a bounded parity check of one synthetic pair of the batch (the -m gpu suite checks all four)
+            from oracle import oracle as O
+            i0n, i1n, u0 = ps[n4 - 1]
+            ou = O.tvl1_global(i0n, i1n, u0, warps=CHECK_WARPS, max_inner=INNER, tol_stop=False)[0]
+            b.solve(warps=CHECK_WARPS, max_inner=INNER, tol_stop=0)
+            leg["pair_3_bit_identical_to_cpu_first_%d_warps" % CHECK_WARPS] = bool(
+                np.array_equal(b.download(n4 - 1).view(np.uint32), ou.view(np.uint32)))
+        out.setdefault("secondary", {})["tvl1_batch_of_4_pairs_per_gpu_configs3_slice"] = leg
+    finally:
+        b.close()
 
 
 def guarded(out, name, fn):
@@ -276,8 +405,10 @@ def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers
     ck = cnt.get("tvl1_chunk_kernel", {})
     wk = cnt.get("tvl1_warp_kernel", {})
     same = (ck.get("tile") == [R, NW] and ck.get("chunk") == K and ck.get("pairs") == npairs and ck.get("size") == [W, H])
-    valu = ck.get("SQ_INSTS_VALU") if same else None
-    traffic = _traffic(ck) if same else None
+    # rocprof's kernel duration has no launch gap in it, the difference timing does (~1.5 us): compare like with like
+    drift_ok = same and within_drift(chunk_us - 1.5, ck.get("avg_us"))
+    valu = ck.get("SQ_INSTS_VALU") if drift_ok else None
+    traffic = _traffic(ck) if drift_ok else None
     algo_bytes = px * BYTES_PER_PX_ITER * iters_per_launch
     TH = R * NW
     per_launch = {
@@ -285,6 +416,7 @@ def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers
         "achieved": round(valu / (chunk_us * 1e-6) / 1e9, 1) if valu else None, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
         "frac": round(valu / (chunk_us * 1e-6) / 1e9 / VALU_PEAK_GINSTR, 4) if valu else None,
         "traffic": traffic, "launch_us": round(chunk_us, 2), "launch_us_rocprof": ck.get("avg_us") if same else None,
+        "counters_used": bool(drift_ok),
         "launch_us_source": "HIP events around whole solves: solve(every launch of this kernel issued twice) - solve, per launch "
                             "= kernel duration + launch gap",
         "valu_instr_per_launch": valu,
@@ -306,9 +438,11 @@ def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers
         pk = cnt.get("tvl1_persist_kernel", {})
         same = (pk.get("tile") == [R, NW] and pk.get("chunk") == K and pk.get("pairs") == npairs and pk.get("size") == [W, H]
                 and pk.get("schedule") == [WARPS, INNER])
-        valu = pk.get("SQ_INSTS_VALU") if same else None
-        traffic = _traffic(pk) if same else None
         kus = pers["kernel_ms"] * 1e3
+        drift = (kus - pk["avg_us"]) / pk["avg_us"] if same and pk.get("avg_us") else None
+        drift_ok = same and within_drift(kus, pk.get("avg_us"))
+        valu = pk.get("SQ_INSTS_VALU") if drift_ok else None
+        traffic = _traffic(pk) if drift_ok else None
         roof = {"bound": "valu", "kernel": "tvl1_persist_kernel<%d,%d>" % (R, NW),
                 "achieved": round(valu / (kus * 1e-6) / 1e9, 1) if valu else None,
                 "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
@@ -317,12 +451,16 @@ def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers
                 "launch_us": round(kus, 1),
                 "launch_us_source": "HIP event pair around the launch, on the library's stream (one launch = one whole solve)",
                 "launch_us_rocprof": pk.get("avg_us") if same else None,
+                "launch_us_drift": round(drift, 4) if drift is not None else None,
+                "counters_used": bool(drift_ok),
+                "counters_refused": None if drift_ok else (cnt.get("_stale") or ("no counters for this schedule" if not same else
+                                                          "live duration is more than %d %% away from the profiled one" % int(DRIFT_LIMIT * 100))),
                 "valu_instr_per_launch": valu,
                 "valu_instr_per_useful_px_iter": round(valu * 64 / step_px_iters, 1) if valu else None,
                 "owned_over_computed_px": round((64 - 2 * K) * (TH - 2 * HY) / float(64 * TH), 3),
                 "inner_iters_per_launch": WARPS * INNER, "iters_between_halo_exchanges": K,
                 "us_per_warp": round(kus / WARPS, 2),
-                "counters_file": os.path.relpath(COUNTERS_JSON, ROOT) if same else None,
+                "counters_file": os.path.relpath(COUNTERS_JSON, ROOT) if drift_ok else None,
                 "note": "every tile stays in registers for the whole solve; workgroups exchange halos through HBM every %d "
                         "iterations.  Bound by vector-ALU issue, not by HBM (roofline_hbm is the view the north star asks for); "
                         "achieved counts EXECUTED instructions, halo recomputation included" % K}
@@ -348,9 +486,13 @@ def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers
            "whole_step": {"algorithmic_bytes": int(step_bytes), "ms": round(solve_ms, 3),
                           "effective_GBps": round(step_bytes / (solve_ms * 1e-3) / 1e9, 1),
                           "effective_frac": round(step_bytes / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-    if roof["frac"] is not None:
-        assert roof["frac"] <= 1.0, "VALU roofline fraction above 1: counters file does not belong to this kernel"
-    return {
+    errors = {}
+    if roof["frac"] is not None and roof["frac"] > 1.0:      # recorded, never fatal: the headline must not be lost to a stale profile
+        errors["roofline"] = "VALU roofline fraction %.3f above 1: the counters file does not belong to this kernel" % roof["frac"]
+        roof["frac"] = roof["achieved"] = roof["traffic"] = None
+    if cnt.get("_stale"):
+        errors["counters"] = cnt["_stale"]
+    line = {
         "metric": "Mpixels*warp-iters/sec on TV-L1 global_faldoi, Sintel 1024x436; EPE vs CPU ref",
         "value": round(value, 1), "unit": "Mpx*iter/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 3),
@@ -368,6 +510,9 @@ def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers
         "per_launch_path": per_launch if pers else None,
         "launches_per_step": launches / float(args.steps),
     }
+    if errors:
+        line["secondary_errors"] = errors
+    return line
 
 
 def cpu_baseline_leg(out, F, np, batch, pairs):

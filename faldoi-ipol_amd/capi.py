@@ -18,7 +18,7 @@ MAX_CHUNK = 16
 # every symbol include/faldoi_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "faldoi_abi_version", "faldoi_device_count", "faldoi_ctx_create", "faldoi_ctx_destroy",
-    "faldoi_ctx_synchronize", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
+    "faldoi_ctx_synchronize", "faldoi_ctx_persist_stats", "faldoi_ctx_persist_retry", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
     "faldoi_tvl1_batch_create", "faldoi_tvl1_batch_destroy", "faldoi_tvl1_batch_upload",
     "faldoi_tvl1_batch_reset", "faldoi_tvl1_batch_solve", "faldoi_tvl1_batch_download",
     "faldoi_tvl1_batch_last_timing", "faldoi_tvl1_batch_last_schedule", "faldoi_tvl1_batch_last_persistent", "faldoi_tvl1_schedule_query", "faldoi_centered_gradient", "faldoi_forward_gradient",
@@ -99,6 +99,8 @@ def lib():
     L.faldoi_ctx_destroy.argtypes = [vp]
     L.faldoi_ctx_destroy.restype = None
     L.faldoi_ctx_synchronize.argtypes = [vp]
+    L.faldoi_ctx_persist_stats.argtypes = [vp] + [C.POINTER(C.c_long)] * 4
+    L.faldoi_ctx_persist_retry.argtypes = [vp]
     L.faldoi_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
     L.faldoi_tvl1_default_params.restype = None
     L.faldoi_tvl1_global.argtypes = [vp, _F, _F, _F, vp, C.c_int, C.c_int, C.POINTER(Tvl1Params),
@@ -206,6 +208,15 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def persist_stats(self):
+        """dict(launches, fallbacks, busy, backed_off): this context's history with the persistent TV-L1 kernel."""
+        v = [C.c_long() for _ in range(4)]
+        _check(lib().faldoi_ctx_persist_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("launches", "fallbacks", "busy", "backed_off"), (x.value for x in v)))
+
+    def persist_retry(self):
+        _check(lib().faldoi_ctx_persist_retry(self._h))
 
     # ---- primitives (host arrays in/out) ----
     def centered_gradient(self, img):

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -116,7 +117,67 @@ struct faldoi_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int *h_done = nullptr;            // pinned
     int n_cu = 256;
+    // What this context has seen of the persistent TV-L1 kernel (tvl1_persist_kernel.hpp), faldoi_ctx_persist_stats:
+    long persist_launches = 0;        // solves that ran as one persistent launch
+    long persist_fallbacks = 0;       // launches that gave up waiting (workgroups not all resident) and were redone per launch
+    long persist_busy = 0;            // solves kept off the persistent path because the device had other work of this process
+    long persist_backed_off = 0;      // solves kept off it while backing off after a give-up
+    int persist_backoff = 0;          // such solves still to come before the persistent path is tried again
+    int persist_backoff_len = 0;      // length of the current back-off: 16, doubling per consecutive give-up up to 1024; 0 = none
 };
+
+// ------------------------------------------------------------------------------------------ who else is on the device
+// The persistent kernel needs every one of its workgroups resident at once (one per CU); whatever else holds CUs while it
+// starts can keep some of them out, and two persistent grids can each hold half the chip and wait for the other half.  Inside
+// one process the library knows what it has in flight: every compute entry point counts itself in and out per device, and a
+// solve takes the persistent path only if it is alone on the device at that moment -- the contract of include/faldoi_hip.h
+// ("distinct contexts may be used from distinct host threads") then costs the second thread nothing but the per-launch
+// path.  Other processes (or another library) on the same device are not visible here: the bounded spin of the kernel and the
+// per-context back-off above cover them.
+namespace {
+constexpr int kMaxDevices = 64;
+struct DeviceGate {
+    std::mutex m;
+    int active = 0;                   // compute entry points of this library running on the device right now (any context / thread)
+    bool persist = false;             // one of them is a persistent TV-L1 grid
+};
+DeviceGate g_gate[kMaxDevices];
+
+class OpScope {                       // RAII: an entry point's stay on a device
+public:
+    explicit OpScope(const faldoi_ctx *c) : g_(c ? &g_gate[(unsigned)c->device % kMaxDevices] : nullptr)
+    {
+        if (!g_) return;
+        std::lock_guard<std::mutex> lk(g_->m);
+        ++g_->active;
+    }
+    ~OpScope()
+    {
+        if (!g_) return;
+        std::lock_guard<std::mutex> lk(g_->m);
+        --g_->active;
+        if (persist_) g_->persist = false;
+    }
+    bool try_persist()                // true: the caller is alone on the device and now holds the persistent slot
+    {
+        if (!g_) return false;
+        std::lock_guard<std::mutex> lk(g_->m);
+        if (!persist_ && g_->active == 1 && !g_->persist) g_->persist = persist_ = true;
+        return persist_;
+    }
+    void release_persist()
+    {
+        if (!g_ || !persist_) return;
+        std::lock_guard<std::mutex> lk(g_->m);
+        g_->persist = persist_ = false;
+    }
+    OpScope(const OpScope &) = delete;
+    OpScope &operator=(const OpScope &) = delete;
+private:
+    DeviceGate *g_;
+    bool persist_ = false;
+};
+}  // namespace
 
 struct faldoi_tvl1_batch {
     faldoi_ctx *ctx = nullptr;
@@ -144,7 +205,7 @@ struct faldoi_tvl1_batch {
     unsigned *xflags = nullptr;       // its epoch flags + abort word, then the error boards of the tolerance-stop form
     size_t xflags_bytes = 0;
     int last_persistent = 0;
-    bool persist_off = false;         // the persistent kernel once gave up on this batch (its workgroups were not all resident)
+    bool persist_off = false;         // the persistent kernel cannot be launched for this batch (e.g. the device's LDS cannot hold the snapshot)
 };
 
 static int check_device(int *count)
@@ -228,6 +289,24 @@ extern "C" int faldoi_ctx_synchronize(faldoi_ctx *c)
     if (!c) return fail(FALDOI_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_ctx_persist_stats(faldoi_ctx *c, long *launches, long *fallbacks, long *busy, long *backed_off)
+{
+    if (!c) return fail(FALDOI_ERR_INVALID, "ctx is NULL");
+    if (launches) *launches = c->persist_launches;
+    if (fallbacks) *fallbacks = c->persist_fallbacks;
+    if (busy) *busy = c->persist_busy;
+    if (backed_off) *backed_off = c->persist_backed_off;
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_ctx_persist_retry(faldoi_ctx *c)
+{
+    if (!c) return fail(FALDOI_ERR_INVALID, "ctx is NULL");
+    c->persist_backoff = 0;
+    c->persist_backoff_len = 0;
     return FALDOI_OK;
 }
 
@@ -343,7 +422,7 @@ static bool pick_persist(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *p
 {
     if (const char *on = getenv("FALDOI_PERSIST"))                        // FALDOI_PERSIST=0: always the per-launch path
         if (atoi(on) <= 0) return false;
-    if (b->persist_off) return false;                                     // a launch of this batch timed out before
+    if (b->persist_off) return false;                                     // a launch for this batch was refused by the runtime
     if (b->npairs != 1) return false;
     const bool dynamic = prm->tol_stop != 0;                              // tvl1_persist_dyn_kernel.hpp: built for 64x48 tiles only
     if (const char *s = getenv("FALDOI_PERSIST_CFG")) {                   // tuning aid: R,NW,k
@@ -504,7 +583,7 @@ static int ensure(void **p, size_t *have, size_t want_bytes)
     return FALDOI_OK;
 }
 
-static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, faldoi_tvl1_stats *stats)
+static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, faldoi_tvl1_stats *stats, OpScope &scope)
 {
     if (!b || !prm) return fail(FALDOI_ERR_INVALID, "NULL argument");
     for (int i = 0; i < b->npairs; ++i)
@@ -526,7 +605,16 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     int chunk;
     pick_schedule(b, prm, &tc, &chunk);
     PersistCfg pc{ 0, 0, 0, 0 };
-    const bool persist = pick_persist(b, prm, &pc);
+    bool persist = pick_persist(b, prm, &pc);
+    if (persist && c->persist_backoff > 0) {    // a recent launch gave up (its workgroups were not all resident): per-launch path for a while
+        --c->persist_backoff;
+        ++c->persist_backed_off;
+        persist = false;
+    }
+    if (persist && !scope.try_persist()) {      // something else of this process is on the device (another thread's solve or growing)
+        ++c->persist_busy;
+        persist = false;
+    }
     if (persist) {
         tc = TileCfg{ pc.R, pc.NW };
         chunk = pc.k;
@@ -643,8 +731,11 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         a.xslab = b->xslab;
         a.xslab_bytes = (unsigned)slab_bytes;
         a.flags = b->xflags;
-        a.spin_limit = 400000u;                                    // ~0.5 s of polling: a lost workgroup, not a slow one
-        if (const char *v = getenv("FALDOI_PERSIST_SPINS")) { const long q = atol(v); if (q > 0 && q < (1L << 31)) a.spin_limit = (unsigned)q; }
+        // ~1.2 us per poll: 40 000 polls = ~50 ms.  A neighbour lags by one chunk of iterations at most (tens of microseconds), so this
+        // long a wait means a workgroup that is not resident, not a slow one.  FALDOI_PERSIST_SPINS=0 (test hook): every tile gives
+        // up at its first exchange, before it polls
+        a.spin_limit = 40000u;
+        if (const char *v = getenv("FALDOI_PERSIST_SPINS")) { const long q = atol(v); if (q >= 0 && q < (1L << 31)) a.spin_limit = (unsigned)q; }
         a.stamps = p_stamps;
         a.stamp_warp = warps / 2;
         a.err_board = b->xflags + flag_words;
@@ -659,7 +750,8 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         if ((dynamic ? launch_persist_dyn(pc, grid, s, a) : launch_persist(pc, grid, s, a)) != hipSuccess) {
             (void)hipGetLastError();                               // e.g. a device whose LDS cannot hold the snapshot: per-launch path
             b->persist_off = true;
-            return faldoi_tvl1_batch_solve_impl(b, prm, stats);
+            scope.release_persist();
+            return faldoi_tvl1_batch_solve_impl(b, prm, stats, scope);
         }
         HIP_TRY(hipEventRecord(b->ev[1], s));
         ev_used = 2;
@@ -742,15 +834,23 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         chunk_ms += t;
     }
 
+    if (persist) scope.release_persist();       // the grid has drained (the event above): the device is free for the next one
     if (persist && *c->h_done != 0) {
-        // Bounded spins: a tile that waited ~0.5 s for a neighbour raised the abort word and every workgroup left.  The cause is
-        // residency (another kernel held CUs this grid needed), not the data: run this batch on the per-launch path from now on.
-        static std::atomic<bool> told{ false };
-        if (!told.exchange(true))
-            fprintf(stderr, "faldoi: the persistent TV-L1 kernel gave up waiting for a neighbouring tile (first at tile %d): its "
-                            "workgroups were not all resident; using the per-launch path\n", *c->h_done - 1);
-        b->persist_off = true;
-        return faldoi_tvl1_batch_solve_impl(b, prm, stats);
+        // Bounded spins: a tile that waited ~50 ms for a neighbour raised the abort word and every workgroup left.  The cause is
+        // residency (something else held CUs this grid needed -- another process, a CU mask), not the data: the solve is redone on
+        // the per-launch path, and this context stays there for the next 16 solves (doubling per consecutive give-up, up to 1024)
+        // before it tries again.  Counted in faldoi_ctx_persist_stats; said on stderr every time (the back-off bounds how often).
+        ++c->persist_fallbacks;
+        c->persist_backoff_len = c->persist_backoff_len ? (c->persist_backoff_len < 1024 ? 2 * c->persist_backoff_len : 1024) : 16;
+        c->persist_backoff = c->persist_backoff_len + 1;           // + the redo below
+        fprintf(stderr, "faldoi: the persistent TV-L1 kernel gave up waiting for a neighbouring tile (first at tile %d): its workgroups "
+                        "were not all resident; using the per-launch path for this and the next %d solves of this context (give-up %ld)\n",
+                *c->h_done - 1, c->persist_backoff_len, c->persist_fallbacks);
+        return faldoi_tvl1_batch_solve_impl(b, prm, stats, scope);
+    }
+    if (persist) {
+        ++c->persist_launches;
+        c->persist_backoff_len = 0;
     }
     if (p_stamps_out) {
         std::vector<unsigned long long> hs((size_t)kPersistStamps * ntiles);
@@ -858,7 +958,10 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
 
 extern "C" int faldoi_tvl1_batch_solve(faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, faldoi_tvl1_stats *stats)
 {
-    return abi_guard("the TV-L1 solve", [&] { return faldoi_tvl1_batch_solve_impl(b, prm, stats); });
+    return abi_guard("the TV-L1 solve", [&] {
+        OpScope scope(b ? b->ctx : nullptr);
+        return faldoi_tvl1_batch_solve_impl(b, prm, stats, scope);
+    });
 }
 
 extern "C" int faldoi_tvl1_batch_last_timing(faldoi_tvl1_batch *b, double *solve_ms, int *chunk_launches, long *px_iters,
@@ -1284,7 +1387,10 @@ static int faldoi_nltvcsad_global_impl(faldoi_ctx *ctx, const float *I0, const f
 extern "C" int faldoi_nltvcsad_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
                                       int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
 {
-    return abi_guard("the NLTV-CSAD solver", [&] { return faldoi_nltvcsad_global_impl(ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms); });
+    return abi_guard("the NLTV-CSAD solver", [&] {
+        OpScope scope(ctx);
+        return faldoi_nltvcsad_global_impl(ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms);
+    });
 }
 
 extern "C" void faldoi_nltvl1_default_params(faldoi_nltvcsad_params *p)
@@ -1303,7 +1409,10 @@ static int faldoi_nltvl1_global_impl(faldoi_ctx *ctx, const float *I0, const flo
 extern "C" int faldoi_nltvl1_global(faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
                                     int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
 {
-    return abi_guard("the NLTV-L1 solver", [&] { return faldoi_nltvl1_global_impl(ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms); });
+    return abi_guard("the NLTV-L1 solver", [&] {
+        OpScope scope(ctx);
+        return faldoi_nltvl1_global_impl(ctx, I0, I1, a, pd, nx, ny, prm, u, solve_ms);
+    });
 }
 
 static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
@@ -1508,7 +1617,10 @@ static int faldoi_local_tvl1_interpolate_impl(faldoi_local_tvl1 *h, int npatches
 
 extern "C" int faldoi_local_tvl1_interpolate(faldoi_local_tvl1 *h, int npatches, const int *patches)
 {
-    return abi_guard("the window filling", [&] { return faldoi_local_tvl1_interpolate_impl(h, npatches, patches); });
+    return abi_guard("the window filling", [&] {
+        OpScope scope(h ? h->ctx : nullptr);
+        return faldoi_local_tvl1_interpolate_impl(h, npatches, patches);
+    });
 }
 
 static int faldoi_local_tvl1_estimate_impl(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
@@ -1531,7 +1643,10 @@ static int faldoi_local_tvl1_estimate_impl(faldoi_local_tvl1 *h, int npatches, c
 extern "C" int faldoi_local_tvl1_estimate(faldoi_local_tvl1 *h, int npatches, const int *patches, int max_iter_patch,
                                           float *ener_out, int *iters_out)
 {
-    return abi_guard("the local operator", [&] { return faldoi_local_tvl1_estimate_impl(h, npatches, patches, max_iter_patch, ener_out, iters_out); });
+    return abi_guard("the local operator", [&] {
+        OpScope scope(h ? h->ctx : nullptr);
+        return faldoi_local_tvl1_estimate_impl(h, npatches, patches, max_iter_patch, ener_out, iters_out);
+    });
 }
 
 // ------------------------------------------------------------------------------------------ self-test

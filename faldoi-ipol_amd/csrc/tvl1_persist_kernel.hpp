@@ -19,9 +19,10 @@
 // loads the bytes with sc1 loads only (bypass L1; the lines are not in this XCD's L2 before the first load after the
 // store, because sc1 stores drop them).  No handed-off byte is ever read by a plain load inside the launch.
 //
-// Residency: one workgroup per tile, tiles <= CUs (host-checked), plain launch.  Every spin is bounded: after `spin_limit`
-// polls a workgroup raises the abort word and returns; every poller also watches the abort word, so the grid drains and the
-// host reports FALDOI_ERR_HIP instead of hanging.
+// Residency: one workgroup per tile, tiles <= CUs (host-checked), plain launch, and the host only takes this path when nothing
+// else of the process is on the device (faldoi_hip.hip, DeviceGate).  Every spin is bounded: after `spin_limit` polls a workgroup
+// raises the abort word and returns; every poller also watches the abort word, so the grid drains and the host redoes the solve
+// on the per-launch path instead of hanging.
 #pragma once
 #include "tvl1_kernels.hpp"
 
@@ -266,6 +267,10 @@ __device__ __forceinline__ bool px_wait(const unsigned *flags, unsigned *abort_w
     const int ax = txi + d % 3 - 1, ay = tyi + d / 3 - 1;
     const bool has = lane < 8 && ax >= 0 && ax < ntx && ay >= 0 && ay < nty;
     const unsigned *pw = (lane == 8) ? abort_word : flags + (size_t)(has ? ay * ntx + ax : t) * kFlagStride;
+    if (spin_limit == 0u) {                                       // test hook (FALDOI_PERSIST_SPINS=0): give up before the first poll
+        if (lane == 0) __hip_atomic_store(abort_word, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    }
     for (unsigned spins = 0;; ++spins) {
         bool behind = false, aborted = false;
         if (!all) {

@@ -12,8 +12,9 @@
  *   - plain C types only; every function returns an int status (FALDOI_OK == 0) and never
  *     throws or aborts (the reference's void functions abort()/assert on failure);
  *   - a faldoi_ctx owns one device + one HIP stream + workspaces; distinct contexts may be used
- *     from distinct host threads, one context is not thread-safe (mirrors the reference's
- *     per-thread SpecificOFStuff/OpticalFlowData ownership, src/local_faldoi.cpp:1192-1219);
+ *     from distinct host threads at the same time, also on one device (tested: tests/test_gpu_parity.py,
+ *     "threads"); one context is not thread-safe (mirrors the reference's per-thread
+ *     SpecificOFStuff/OpticalFlowData ownership, src/local_faldoi.cpp:1192-1219,1305-1347);
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point returns
  *     FALDOI_ERR_NO_DEVICE.
  */
@@ -83,6 +84,14 @@ int faldoi_device_count(int *count);
 int faldoi_ctx_create(int device, faldoi_ctx **out);
 void faldoi_ctx_destroy(faldoi_ctx *ctx);
 int faldoi_ctx_synchronize(faldoi_ctx *ctx);
+/* The persistent TV-L1 kernel (one launch per solve, see faldoi_tvl1_batch_last_persistent) needs all its workgroups resident at
+ * once, so a solve takes it only when nothing else of this process is running on the device (any context, any thread); a second
+ * thread's solve runs on the per-launch path meanwhile (`busy`).  Work of OTHER processes on the device is invisible to the
+ * library: a launch that waits ~50 ms for a workgroup gives up, the solve is redone per launch (`fallbacks`, a line on stderr),
+ * and the context stays on the per-launch path for the next 16 solves (doubling per consecutive give-up up to 1024: `backed_off`).
+ * Counters are per context, since its creation; any pointer may be NULL.  faldoi_ctx_persist_retry ends a back-off now. */
+int faldoi_ctx_persist_stats(faldoi_ctx *ctx, long *launches, long *fallbacks, long *busy, long *backed_off);
+int faldoi_ctx_persist_retry(faldoi_ctx *ctx);
 /* Thread-local text of the last failure (HIP error string, argument that was rejected). */
 const char *faldoi_last_error(void);
 void faldoi_tvl1_default_params(faldoi_tvl1_params *p);

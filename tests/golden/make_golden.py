@@ -12,6 +12,9 @@ Also committed next to it:
                                            GPU == oracle test; no reference output recorded for it).
   known_answers.json                    -- what the compiled reference produced for whole solves
                                            (iteration counts, sha256 of the .flo), SURVEY.md App. D.
+  sintel_{clean_easy,final_hard}_gt_frame_0002.npz -- the ground-truth flows the reference ships beside those frames
+                                           (example_data/*/*/gt/frame_0002.flo; data files, re-packed planar (2,h,w) by
+                                           ground_truth() below): the accuracy anchors of the suite (EPE vs GT).
 """
 import os
 import sys
@@ -169,6 +172,17 @@ def models():
     print("wrote ref_models.npz with", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "ref_models.npz")), "bytes")
 
 
+def ground_truth():
+    """The reference's ground-truth flows of its two example pairs we keep frames of, planar (2, h, w) float32."""
+    import faldoi_ipol_amd as F
+    for sub, tag in (("clean/easy", "sintel_clean_easy"), ("final/hard", "sintel_final_hard")):
+        gt = F.flo.read_flo("/root/reference/example_data/%s/gt/frame_0002.flo" % sub)
+        dst = os.path.join(HERE, "%s_gt_frame_0002.npz" % tag)
+        np.savez_compressed(dst, gt=gt)
+        print("wrote", os.path.basename(dst), gt.shape, os.path.getsize(dst), "bytes")
+
+
 if __name__ == "__main__":
     main()
     models()
+    ground_truth()

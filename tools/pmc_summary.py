@@ -29,11 +29,30 @@ FAMILIES = {            # JSON key -> substring of the demangled kernel name
 KB_COUNTERS = ("FETCH_SIZE", "WRITE_SIZE")
 
 
-def family(name):
+def families(name, grid, want_grid):
+    """JSON keys a dispatch counts for: its family, when no grid filter is set for it or the grid matches, and every
+    `family@tag` entry whose grid matches (the bench's secondary legs launch the same kernels on other schedules)."""
+    keys = []
     for key, sub in FAMILIES.items():
-        if sub in name:
-            return key
-    return None
+        if sub not in name:
+            continue
+        if key not in want_grid or want_grid[key] == grid:
+            keys.append(key)
+        keys += [k for k, g in want_grid.items() if k.startswith(key + "@") and g == grid]
+    return keys
+
+
+def source_hash():
+    """The stamp bench.py compares (bench.kernel_source_hash): sha256 over csrc/*.hip|hpp|inc."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "faldoi-ipol_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".inc")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -42,9 +61,11 @@ def main():
     ap.add_argument("--label", default="")
     ap.add_argument("--chunk-tile", default="", help="R,NW,chunk,pairs,W,H of the chunk kernel's schedule in these runs")
     ap.add_argument("--persist-tile", default="", help="R,NW,k,pairs,WxH,warps,inner of the persistent kernel's schedule in these runs")
-    ap.add_argument("--grid", action="append", default=[], metavar="FAMILY=THREADS",
+    ap.add_argument("--tile", action="append", default=[], metavar="KEY=R,NW,chunk,pairs,WxH",
+                    help="the schedule behind another chunk-kernel entry (KEY = tvl1_chunk_kernel@tag)")
+    ap.add_argument("--grid", action="append", default=[], metavar="FAMILY[@TAG]=THREADS",
                     help="count only the dispatches of FAMILY whose grid has THREADS work-items (the bench's secondary legs launch the "
-                         "same kernels on other sizes)")
+                         "same kernels on other sizes); FAMILY@TAG=THREADS adds a second entry of that family for another grid")
     ap.add_argument("dirs", nargs="+")
     a = ap.parse_args()
     want_grid = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.grid}
@@ -58,30 +79,27 @@ def main():
             pmc_passes += 1
             with open(path, newline="") as f:
                 for row in csv.DictReader(f):
-                    fam = family(row["Kernel_Name"])
-                    if not fam or (fam in want_grid and int(row["Grid_Size"]) != want_grid[fam]):
-                        continue
-                    s = acc.setdefault(fam, {}).setdefault(row["Counter_Name"], [0.0, 0])
-                    s[0] += float(row["Counter_Value"])
-                    s[1] += 1
-                    m = meta.setdefault(fam, {})
-                    m["name"] = row["Kernel_Name"].split("(")[0].replace("void ", "")
-                    m["grid_threads"] = int(row["Grid_Size"])
-                    m["workgroup"] = int(row["Workgroup_Size"])
-                    m["vgprs"] = int(row["VGPR_Count"])
-                    m["lds_bytes"] = int(row["LDS_Block_Size"])
+                    for fam in families(row["Kernel_Name"], int(row["Grid_Size"]), want_grid):
+                        s = acc.setdefault(fam, {}).setdefault(row["Counter_Name"], [0.0, 0])
+                        s[0] += float(row["Counter_Value"])
+                        s[1] += 1
+                        m = meta.setdefault(fam, {})
+                        m["name"] = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                        m["grid_threads"] = int(row["Grid_Size"])
+                        m["workgroup"] = int(row["Workgroup_Size"])
+                        m["vgprs"] = int(row["VGPR_Count"])
+                        m["lds_bytes"] = int(row["LDS_Block_Size"])
         if not cc:                                # a duration pass: kernel-trace only (counters perturb durations)
             for path in kt:
                 with open(path, newline="") as f:
                     for row in csv.DictReader(f):
-                        fam = family(row["Kernel_Name"])
                         grid = int(row["Grid_Size_X"]) * int(row["Grid_Size_Y"]) * int(row["Grid_Size_Z"])
-                        if not fam or (fam in want_grid and grid != want_grid[fam]):
-                            continue
-                        s = acc.setdefault(fam, {}).setdefault("_dur_ns", [0.0, 0])
-                        s[0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
-                        s[1] += 1
-    out = {"_label": a.label, "_source": [os.path.relpath(d) for d in a.dirs], "_pmc_passes": pmc_passes}
+                        for fam in families(row["Kernel_Name"], grid, want_grid):
+                            s = acc.setdefault(fam, {}).setdefault("_dur_ns", [0.0, 0])
+                            s[0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                            s[1] += 1
+    out = {"_label": a.label, "_source": [os.path.relpath(d) for d in a.dirs], "_pmc_passes": pmc_passes,
+           "_source_hash": source_hash()}
     for fam, counters in acc.items():
         e = dict(meta.get(fam, {}))
         for c, (tot, n) in sorted(counters.items()):
@@ -96,6 +114,11 @@ def main():
     if a.chunk_tile and "tvl1_chunk_kernel" in out:
         r, nw, k, pairs, w, h = (int(x) for x in re.split("[,x]", a.chunk_tile))
         out["tvl1_chunk_kernel"].update({"tile": [r, nw], "chunk": k, "pairs": pairs, "size": [w, h]})
+    for kv in a.tile:
+        key, val = kv.split("=")
+        if key in out:
+            r, nw, k, pairs, w, h = (int(x) for x in re.split("[,x]", val))
+            out[key].update({"tile": [r, nw], "chunk": k, "pairs": pairs, "size": [w, h]})
     if a.persist_tile and "tvl1_persist_kernel" in out:
         r, nw, k, pairs, w, h, warps, inner = (int(x) for x in re.split("[,x]", a.persist_tile))
         out["tvl1_persist_kernel"].update({"tile": [r, nw], "chunk": k, "pairs": pairs, "size": [w, h], "schedule": [warps, inner]})
