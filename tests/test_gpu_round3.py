@@ -307,8 +307,9 @@ def test_accuracy_anchor_tvl1_zero_init_epe_vs_ground_truth(ctx):
 def test_accuracy_anchors_other_global_functionals(ctx):
     """NLTV-L1, TV-CSAD and NLTV-CSAD have no recorded reference output at full size (their loops live in a file this image
     cannot compile); what the reference does hold for them is the ground truth of its example pair.  A zero-initialised global
-    minimisation must land where TV-L1 does (EPE 1.04, from 2.98 for the zero flow): the bounds below are the values this
-    build returns (bit-identical to the CPU restatement, tests above) +- 2 %, so any change of the arithmetic shows here."""
+    minimisation from a zero flow must move towards it (2.98 for the zero flow; TV-L1 reaches 1.04, these functionals with the
+    parameters main forces for them 1.7-1.9 after five warps): the values below are what this build returns -- bit-identical to
+    the CPU restatement wherever that is affordable (tests above) -- so any change of the arithmetic at full size shows here."""
     i0, i1 = sintel_pair()
     i0n, i1n = ctx.preprocess_global(i0, i1)
     lab = F.capi.image_to_lab(i0)
@@ -322,9 +323,9 @@ def test_accuracy_anchors_other_global_functionals(ctx):
     print("EPE vs ground truth, clean/easy, zero init, 5 warps:", got)
     for name, v in got.items():
         want = ANCHORS[name]
-        assert 0.5 < v < 2.0, (name, v)                                   # the neighbourhood of TV-L1's 1.04
-        assert abs(v - want) <= 0.02 * want, (name, v, want)
+        assert 0.5 < v < 2.0, (name, v)                                   # better than the zero flow by a pixel or more
+        assert abs(v - want) <= 1e-3, (name, v, want)
 
 
-# measured on MI355X with this build (tools/accuracy_anchors.py prints them); see the test above
-ANCHORS = {"nltvl1": None, "tvcsad": None, "nltvcsad": None}
+# measured on MI355X (round 3, gpurun_out/r3_gputest1.log); the test prints the current values
+ANCHORS = {"nltvl1": 1.71843, "tvcsad": 1.68424, "nltvcsad": 1.86763}
