@@ -86,7 +86,9 @@ def lib():
     if _lib is not None:
         return _lib
     so = _build.SO
-    if _build.needs_build():
+    if os.environ.get("FALDOI_LIB"):                  # development aid: a timing-only build of the library (tools/nl_whatif.sh)
+        so = os.environ["FALDOI_LIB"]
+    elif _build.needs_build():
         so = _build.build()
     if not os.path.exists(so):
         raise RuntimeError("libfaldoi_hip.so is missing and could not be built; the HIP path has no fallback")

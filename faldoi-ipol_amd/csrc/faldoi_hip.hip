@@ -9,6 +9,7 @@
 #include "tvl1_persist_dyn_kernel.hpp"
 #include "preprocess_kernels.hpp"
 #include "nltv_kernels.hpp"
+#include "nltv_fused_kernel.hpp"
 #include "local_kernels.hpp"
 #include "grow_kernels.hpp"
 
@@ -1415,6 +1416,53 @@ extern "C" int faldoi_nltvl1_global(faldoi_ctx *ctx, const float *I0, const floa
     });
 }
 
+// Rows per tile of the fused NLTV kernel (64 x rows pixels, one workgroup per CU at a time): the grid runs in
+// ceil(tiles / CUs) rounds of one tile each.  Fewest rounds first, then the taller tile (fewer crossing edges, and a last round
+// that leaves CUs idle runs faster for the others): 1024x436 on 256 CUs -> 16 rows (26.6 ms per 400 iterations; 14 rows, two
+// exact rounds, 26.9; 12 rows, three rounds, 32.0).
+static int nl_pick_rows(int nx, int ny, int n_cu)
+{
+    static const int cand[] = { 16, 14, 12, 8 };
+    int best = 16;
+    long best_rounds = -1;
+    for (int ty : cand) {
+        const long tiles = (long)((nx + kNfW - 1) / kNfW) * ((ny + ty - 1) / ty);
+        const long rounds = (tiles + n_cu - 1) / n_cu;
+        if (best_rounds < 0 || rounds < best_rounds) { best = ty; best_rounds = rounds; }
+    }
+    return best;
+}
+
+template <bool L1, int TY> static hipError_t nl_fused_prepare_t()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&nl_fused_kernel<L1, TY>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)sizeof(NfLds<TY>));
+}
+template <bool L1, int TY> static hipError_t nl_fused_launch_t(hipStream_t s, const NfArgs &a)
+{
+    const int tiles = a.ntx * a.nty;
+    hipLaunchKernelGGL((nl_fused_kernel<L1, TY>), dim3(8 * ((tiles + 7) / 8)), dim3(kNfW * TY), sizeof(NfLds<TY>), s, a);
+    return hipGetLastError();
+}
+#define FALDOI_NL_DISPATCH(fn, ...)                                                       \
+    do {                                                                                  \
+        if (data_l1) {                                                                    \
+            if (ty == 16) return fn<true, 16>(__VA_ARGS__);                               \
+            if (ty == 14) return fn<true, 14>(__VA_ARGS__);                               \
+            if (ty == 12) return fn<true, 12>(__VA_ARGS__);                               \
+            if (ty == 8) return fn<true, 8>(__VA_ARGS__);                                 \
+        } else {                                                                          \
+            if (ty == 16) return fn<false, 16>(__VA_ARGS__);                              \
+            if (ty == 14) return fn<false, 14>(__VA_ARGS__);                              \
+            if (ty == 12) return fn<false, 12>(__VA_ARGS__);                              \
+            if (ty == 8) return fn<false, 8>(__VA_ARGS__);                                \
+        }                                                                                 \
+        return hipErrorInvalidValue;                                                      \
+    } while (0)
+static hipError_t nl_fused_prepare(bool data_l1, int ty) { FALDOI_NL_DISPATCH(nl_fused_prepare_t); }
+static hipError_t nl_fused_launch(bool data_l1, int ty, hipStream_t s, const NfArgs &a) { FALDOI_NL_DISPATCH(nl_fused_launch_t, s, a); }
+#undef FALDOI_NL_DISPATCH
+
 static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
                     int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
 {
@@ -1426,7 +1474,8 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const size_t n = (size_t)nx * ny, nb = n * sizeof(float);
-    const size_t pe = ((n + 63) / 64) * 64;
+    size_t pe = ((n + 63) / 64) * 64;
+    if (const char *v = getenv("FALDOI_NL_PAD")) pe += 64 * (size_t)atoi(v);      // tuning aid: plane stride in units of 256 B
 
     // host tables (threads over row bands)
     std::vector<float> wts((size_t)kNlSlots * n), wt(n);
@@ -1454,12 +1503,33 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
 
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     const float l_t = prm->lambda * prm->theta;                                 // :1659
+    // One fused launch per iteration (nltv_fused_kernel.hpp); FALDOI_NL_FUSED=0 selects the two streaming kernels (same bits).
+    // (the fused kernel addresses the slab through one buffer resource: below 4 GB, i.e. up to ~7.8 Mpx)
+    const bool fused = !(getenv("FALDOI_NL_FUSED") && atoi(getenv("FALDOI_NL_FUSED")) <= 0) &&
+                       (unsigned long long)pe * N_COUNT * sizeof(float) < (1ull << 32) &&
+                       prm->tau < 0x1p35f;                                      // nl_dual_update's argument for |g| below 2^-60
+    NfArgs fa;
+    int ty = 0;
+    if (fused) {
+        ty = nl_pick_rows(nx, ny, ctx->n_cu);
+        if (const char *v = getenv("FALDOI_NL_ROWS")) { const int q = atoi(v); if (q == 8 || q == 12 || q == 14 || q == 16) ty = q; }   // tuning aid
+        fa.base = base; fa.pe = pe; fa.nx = nx; fa.ny = ny;
+        fa.ntx = (nx + kNfW - 1) / kNfW; fa.nty = (ny + ty - 1) / ty;
+        fa.cur = 0; fa.tau = prm->tau; fa.l_t = l_t; fa.theta = prm->theta; fa.rtheta = 1.0 / (double)prm->theta;
+        for (int c = 1; c <= kCsSlots; ++c) fa.kl[c - 1] = (float)(kCsSlots + 2 - 2 * c) * l_t;
+        HIP_TRY(nl_fused_prepare(data_l1, ty));
+    }
     HIP_TRY(hipEventRecord(ctx->ev0, s));
     hipLaunchKernelGGL(centered_gradient_kernel, grid, block, 0, s, base + N_I1 * pe, base + N_I1X * pe, base + N_I1Y * pe,
                        nx, ny, (size_t)0, (size_t)0, 1);                        // :1690
     for (int w = 0; w < prm->warps; ++w) {
-        hipLaunchKernelGGL(nl_warp_kernel, grid, block, 0, s, base, pe, nx, ny, data_l1 ? 1 : 0);
+        hipLaunchKernelGGL(nl_warp_kernel, grid, block, 0, s, base, pe, nx, ny, data_l1 ? 1 : 0, fused ? fa.cur : 0);
         for (int it = 0; it < prm->max_inner; ++it) {                           // :1729 / :1240, no tolerance test
+            if (fused) {
+                HIP_TRY(nl_fused_launch(data_l1, ty, s, fa));
+                fa.cur ^= 1;                                                    // duals and ubar: read one buffer, write the other
+                continue;
+            }
             hipLaunchKernelGGL(nl_dual_kernel, grid, block, 0, s, base, pe, nx, ny, prm->tau);
             if (data_l1)
                 hipLaunchKernelGGL(nl_primal_kernel<true>, grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);

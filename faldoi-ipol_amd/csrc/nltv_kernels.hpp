@@ -32,12 +32,16 @@ enum NlPlane {
     N_W = N_Q + kNlSlots,                  // 24 planes
     N_T1 = N_W + kNlSlots,                 // I1wx*u1 and I1wy*u2 at the start of the warp (CSAD terms)
     N_T2,
-    N_COUNT
+    // second buffers of what the fused kernel (nltv_fused_kernel.hpp) reads from neighbouring tiles while their owners rewrite it
+    N_UBB1, N_UBB2,
+    N_PB,                                  // 24 planes
+    N_QB = N_PB + kNlSlots,                // 24 planes
+    N_COUNT = N_QB + kNlSlots
 };
 
 // Per-warp: three bicubic warps (border_out = true), grad = I1wx^2 + I1wy^2, ubar = u (:1694-1725)
 // data_l1 (NLTV-L1, src/global_faldoi.cpp:1226-1234): the N_I1W plane receives rho_c instead of I1w.
-__global__ __launch_bounds__(256) void nl_warp_kernel(float *__restrict__ base, size_t pe, int nx, int ny, int data_l1)
+__global__ __launch_bounds__(256) void nl_warp_kernel(float *__restrict__ base, size_t pe, int nx, int ny, int data_l1, int cur)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= nx * ny) return;
@@ -56,8 +60,8 @@ __global__ __launch_bounds__(256) void nl_warp_kernel(float *__restrict__ base, 
     base[N_GRAD * pe + p] = grad_sq(wx, wy);
     base[N_T1 * pe + p] = wx * u1;                              // the two products inside b (:1716-1717)
     base[N_T2 * pe + p] = wy * u2;
-    base[N_UB1 * pe + p] = u1;
-    base[N_UB2 * pe + p] = u2;
+    base[(cur ? N_UBB1 : N_UB1) * pe + p] = u1;                 // ubar = u, into the buffer the next iteration reads
+    base[(cur ? N_UBB2 : N_UB2) * pe + p] = u2;
 }
 
 // The CSAD terms of the reference (PosNei::b[48], :1704-1719)

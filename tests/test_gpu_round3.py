@@ -329,3 +329,47 @@ def test_accuracy_anchors_other_global_functionals(ctx):
 
 # measured on MI355X (round 3, gpurun_out/r3_gputest1.log); the test prints the current values
 ANCHORS = {"nltvl1": 1.71843, "tvcsad": 1.68424, "nltvcsad": 1.86763}
+
+
+# ------------------------------------------------------------------ NLTV: one fused launch per iteration (nltv_fused_kernel.hpp)
+def test_fused_nltv_kernel_equals_the_two_kernel_path_and_the_checker(ctx, oracle, monkeypatch):
+    """The fused NLTV kernel keeps a tile's new duals in LDS between the dual and the primal step and recomputes the ring's
+    crossing edges; FALDOI_NL_FUSED=0 is the two streaming kernels of round 2.  Random crops of the example pair -- sizes with one
+    to seven tile columns, ragged last tiles, images smaller than the 5x5 / 7x7 neighbourhoods -- every tile height the host
+    can pick, both data terms: the two paths agree bit for bit, and (small cases) with the CPU checker."""
+    rng = np.random.default_rng(20261005)
+    full0, full1 = sintel_pair()
+    checked = 0
+    for case in range(30):
+        if case < 6:
+            w, h = [(2, 2), (3, 7), (64, 16), (65, 17), (128, 33), (7, 40)][case]
+        else:
+            w, h = int(rng.integers(6, 420)), int(rng.integers(6, 150))
+        x0, y0 = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        c0 = np.ascontiguousarray(full0[:, y0:y0 + h, x0:x0 + w])
+        c1 = np.ascontiguousarray(full1[:, y0:y0 + h, x0:x0 + w])
+        lab = F.capi.image_to_lab(c0)
+        if min(w, h) >= 6:
+            i0n, i1n = oracle.preprocess_global(c0, c1)
+        else:                                    # smaller than the Gaussian's support (the reference aborts there): gray planes as they are
+            i0n, i1n = c0.mean(axis=0) / np.float32(255), c1.mean(axis=0) / np.float32(255)
+        u0 = rng.normal(0, float(rng.choice([0, 0.5, 3.0])), (2, h, w)).astype(np.float32)
+        prm = dict(warps=int(rng.integers(1, 3)), max_inner=int(rng.integers(1, 14)))
+        l1 = case % 3 == 1
+        solve = ctx.nltvl1_global if l1 else ctx.nltvcsad_global
+        monkeypatch.setenv("FALDOI_NL_FUSED", "0")
+        ref = solve(i0n, i1n, lab, u0, **prm)[0]
+        monkeypatch.setenv("FALDOI_NL_FUSED", "1")
+        rows = [None, 8, 12, 14, 16][case % 5]
+        if rows:
+            monkeypatch.setenv("FALDOI_NL_ROWS", str(rows))
+        else:
+            monkeypatch.delenv("FALDOI_NL_ROWS", raising=False)
+        got = solve(i0n, i1n, lab, u0, **prm)[0]
+        assert bits_equal(got, ref), (case, w, h, rows, prm, l1, mismatch_report(got, ref))
+        if w * h <= 6000:
+            want = (oracle.nltvl1_global if l1 else oracle.nltvcsad_global)(i0n, i1n, lab, u0, **prm)
+            want = want[0] if isinstance(want, tuple) else want
+            assert bits_equal(got, want), (case, w, h, mismatch_report(got, want))
+            checked += 1
+    assert checked >= 8

@@ -21,6 +21,7 @@ FAMILIES = {            # JSON key -> substring of the demangled kernel name
     "tvl1_persist_kernel": "tvl1_persist_kernel",
     "tvl1_chunk_kernel": "tvl1_chunk_kernel",
     "tvl1_warp_kernel": "tvl1_warp_kernel",
+    "nl_fused_kernel": "nl_fused_kernel",
     "nl_primal_kernel": "nl_primal_kernel",
     "nl_dual_kernel": "nl_dual_kernel",
     "nl_warp_kernel": "nl_warp_kernel",

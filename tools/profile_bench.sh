@@ -25,7 +25,7 @@ run sq3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD 
 run fetch --kernel-trace --pmc FETCH_SIZE
 run write --kernel-trace --pmc WRITE_SIZE
 python3 tools/pmc_summary.py --out $OUT/counters.json --label "$TAG: python3 bench.py $ARGS" --chunk-tile "$TILE" --persist-tile "$PTILE" \
-    --grid tvl1_persist_kernel=253952 --grid tvl1_chunk_kernel=245760 --grid tvl1_warp_kernel=446464 --grid nl_dual_kernel=446464 --grid nl_primal_kernel=446464 \
+    --grid tvl1_persist_kernel=253952 --grid tvl1_chunk_kernel=245760 --grid tvl1_warp_kernel=446464 --grid nl_fused_kernel=458752 \
     --grid tvl1_chunk_kernel@batch4=778240 --grid tvl1_warp_kernel@batch4=1785856 --tile tvl1_chunk_kernel@batch4=4,8,5,4,1024x436 \
     $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/fetch $OUT/write
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
