@@ -18,12 +18,19 @@ DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HER
 BIN = os.path.join(HERE, "bin")
 HOST = os.path.join(HERE, "host")
 HOST_COMMON = [os.path.join(HOST, "image_io.cpp")]
-HOST_PROGRAMS = {          # name -> (sources, needs libfaldoi_hip)
-    "global_faldoi": ([os.path.join(HOST, "global_faldoi.cpp")], True),
-    "local_faldoi": ([os.path.join(HOST, "local_faldoi.cpp")], True),
-    "faldoi_flow": ([os.path.join(HOST, "faldoi_flow.cpp")], True),
-    "sparse_flow": ([os.path.join(HOST, "sparse_flow.cpp")], False),
-    "faldoi_imginfo": ([os.path.join(HOST, "imginfo.cpp")], False),
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HOST_PROGRAMS = {          # name -> (sources, needs libfaldoi_hip, extra compiler / linker arguments)
+    "global_faldoi": ([os.path.join(HOST, "global_faldoi.cpp")], True, []),
+    "local_faldoi": ([os.path.join(HOST, "local_faldoi.cpp")], True, []),
+    "faldoi_flow": ([os.path.join(HOST, "faldoi_flow.cpp")], True, []),
+    "sparse_flow": ([os.path.join(HOST, "sparse_flow.cpp")], False, []),
+    "faldoi_imginfo": ([os.path.join(HOST, "imginfo.cpp")], False, []),
+    # the multi-GPU batch host: one process per GPU, RCCL directly (plain g++ against the HIP runtime API and RCCL) ...
+    "faldoi_batch": ([os.path.join(HOST, "faldoi_batch.cpp")], True,
+                     ["-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"), "-L" + os.path.join(ROCM, "lib"),
+                      "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-pthread"]),
+    # ... and its rank logic alone for the CPU tests: pipes instead of RCCL, `flow + 1` instead of the solver
+    "faldoi_batch_stub": ([os.path.join(HOST, "faldoi_batch.cpp")], False, ["-DFALDOI_BATCH_STUB", "-pthread"]),
 }
 
 # -ffp-contract=off: parity with the reference CPU path needs un-fused multiply-adds.
@@ -89,7 +96,7 @@ def build_host(force=False, verbose=False):
     hdrs = [os.path.join(HOST, f) for f in ("image_io.hpp", "options.hpp")] + [os.path.join(ROOT, "include", "faldoi_hip.h")]
     out = {}
     with _build_lock():
-        for name, (srcs, needs_lib) in HOST_PROGRAMS.items():
+        for name, (srcs, needs_lib, extra) in HOST_PROGRAMS.items():
             exe = os.path.join(BIN, name)
             out[name] = exe
             deps = srcs + HOST_COMMON + hdrs + ([SO] if needs_lib else [])
@@ -99,7 +106,7 @@ def build_host(force=False, verbose=False):
             cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, "-o", tmp] + srcs + HOST_COMMON
             if needs_lib:
                 cmd += ["-L" + HERE, "-lfaldoi_hip", "-Wl,-rpath,$ORIGIN/.."]
-            cmd += ["-lz"]
+            cmd += extra + ["-lz"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -472,39 +472,74 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
 // ---------------------------------------------------------------------------------------------
 typedef float cand4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) cand4 *heap_ptr;      // the queue lives in global memory: plain global loads
+typedef __attribute__((address_space(3))) cand4 *heap_lds_ptr;
 
-__device__ __forceinline__ void heap_sift_up_wave(heap_ptr h, int hole, const cand4 value)
+// The queue as a growing kernel sees it: while the kernel runs, the first `ntop` elements (the top levels of the binary
+// heap: 2^L - 1 of them) live in LDS -- every pop starts at the root and every sift-up ends near it, so with the levels that
+// fit (L = 13 when the CU holds one growing, 10 with four) a pop makes one or two trips to global memory instead of four to
+// six.  The kernel copies them in when it starts and back when it leaves; the element moves are those of grow_heap.hpp
+// whichever memory an element happens to be in.
+struct HeapRef {
+    heap_ptr g;
+    heap_lds_ptr top;
+    int ntop;
+    __device__ __forceinline__ cand4 ld(int i) const
+    {
+        cand4 v;
+        if (i < ntop) v = top[i];
+        else v = g[i];
+        return v;
+    }
+    __device__ __forceinline__ void st(int i, const cand4 v) const
+    {
+        if (i < ntop) top[i] = v;
+        else g[i] = v;
+    }
+};
+__device__ __forceinline__ HeapRef heap_global_only(Candidate *heap) { return HeapRef{ (heap_ptr)heap, (heap_lds_ptr) nullptr, 0 }; }
+// All threads of the workgroup: the top of a queue of `size` elements into LDS / back (barriers by the caller)
+__device__ __forceinline__ void heap_top_in(const HeapRef &h, int size)
+{
+    const int n = size < h.ntop ? size : h.ntop;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) h.top[k] = h.g[k];
+}
+__device__ __forceinline__ void heap_top_out(const HeapRef &h, int size)
+{
+    const int n = size < h.ntop ? size : h.ntop;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) h.g[k] = h.top[k];
+}
+
+__device__ __forceinline__ void heap_sift_up_wave(const HeapRef &h, int hole, const cand4 value)
 {
     const int lane = threadIdx.x & 63;
     while (hole > 0) {
         const bool have = lane < 24 && ((hole + 1) >> (lane + 1)) > 0;        // lane q <-> q-th ancestor
         const int aidx = have ? ((hole + 1) >> (lane + 1)) - 1 : 0;
-        const cand4 mine = h[aidx];
+        const cand4 mine = h.ld(aidx);
         const unsigned long long down = __builtin_amdgcn_ballot_w64(have && mine.x > value.x);
         const int m = __builtin_ctzll(~down);                                 // leading ancestors that move down
-        if (lane < m) h[((hole + 1) >> lane) - 1] = mine;                     // into the slot of ancestor lane-1 (the hole for lane 0)
+        if (lane < m) h.st(((hole + 1) >> lane) - 1, mine);                   // into the slot of ancestor lane-1 (the hole for lane 0)
         if (m == 0) break;
         hole = ((hole + 1) >> m) - 1;
         if (m < 24) break;
     }
-    if (lane == 0) h[hole] = value;
+    if (lane == 0) h.st(hole, value);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // later loads by OTHER lanes must see these stores
 }
 
-__device__ __forceinline__ void heap_push_wave(Candidate *heap, int &size, int px, int py, float u, float v, float sim)
+__device__ __forceinline__ void heap_push_wave(const HeapRef &h, int &size, int px, int py, float u, float v, float sim)
 {
-    heap_sift_up_wave((heap_ptr)(heap), size, cand4{ sim, u, v, __uint_as_float((unsigned)px | ((unsigned)py << 16)) });
+    heap_sift_up_wave(h, size, cand4{ sim, u, v, __uint_as_float((unsigned)px | ((unsigned)py << 16)) });
     ++size;
 }
 
 // Removes the top (the caller has read element 0); precondition: size > 0.
-__device__ __forceinline__ void heap_remove_top_wave(Candidate *heap, int &size)
+__device__ __forceinline__ void heap_remove_top_wave(const HeapRef &h, int &size)
 {
-    heap_ptr h = (heap_ptr)(heap);
     const int lane = threadIdx.x & 63;
     const int len = --size;
     if (len == 0) return;
-    const cand4 value = h[len];
+    const cand4 value = h.ld(len);
     const int half = (len - 1) / 2;                                 // nodes below `half` have two children
     const int last = len - 1;
     const int d = 31 - __builtin_clz(lane + 2);                     // depth of this lane's node under the hole, 1..5 (6: unused)
@@ -512,7 +547,7 @@ __device__ __forceinline__ void heap_remove_top_wave(Candidate *heap, int &size)
     int hole = 0;
     while (hole < half) {
         const int idx = ((hole + 1) << d) - 1 + off;
-        const cand4 mine = h[(d <= 5 && idx <= last) ? idx : last];
+        const cand4 mine = h.ld((d <= 5 && idx <= last) ? idx : last);
         bool onpath = false;
         int cur = hole, rel = 0;                                    // rel: position of `cur` within its level of the subtree
 #pragma unroll
@@ -526,14 +561,14 @@ __device__ __forceinline__ void heap_remove_top_wave(Candidate *heap, int &size)
                 rel = 2 * rel + right;
             }
         }
-        if (onpath) h[(idx - 1) >> 1] = mine;                       // every element of the path moves into its parent's slot
+        if (onpath) h.st((idx - 1) >> 1, mine);                     // every element of the path moves into its parent's slot
         hole = cur;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if ((len & 1) == 0 && hole == (len - 2) / 2) {                  // the one node with a single (left) child
         const int child = 2 * (hole + 1);
-        const cand4 c = h[child - 1];
-        if (lane == 0) h[hole] = c;
+        const cand4 c = h.ld(child - 1);
+        if (lane == 0) h.st(hole, c);
         hole = child - 1;
     }
     heap_sift_up_wave(h, hole, value);
@@ -544,7 +579,7 @@ __device__ __forceinline__ void heap_remove_top_wave(Candidate *heap, int &size)
 // 2: CSAD alone (-m 4, 5); 3: non-local + CSAD (-m 6); 4: non-local + CSAD over sqrt(|grad|^2) (-m 7).
 template <int FN>
 __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, const GrowDir &D, size_t pe, int nx, int ny, int i, int j,
-                                                  int iteration, int wr, int max_iter_patch, int &heap_size,
+                                                  int iteration, int wr, int max_iter_patch, const HeapRef &heap, int &heap_size,
                                                   long long &fills, long long *cyc)
 {
     const int t = threadIdx.x;
@@ -609,7 +644,7 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
             if (!nfix[q] && new_ener < nene[q]) {                                 // outside the image: nfix = 1 (wave-uniform test)
                 if (t == 0) D.ene[py * nx + px] = ener0;
                 const int wq = (py - ij) * pw + (px - ii);                        // the neighbour lies in the window
-                if (heap_size < D.heap_cap) heap_push_wave(D.heap, heap_size, px, py, sm.a[wq], sm.b[wq], new_ener);
+                if (heap_size < D.heap_cap) heap_push_wave(heap, heap_size, px, py, sm.a[wq], sm.b[wq], new_ener);
                 else if (t == 0) D.ctl->overflow = 1;
             }
         }
@@ -631,9 +666,13 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
 // mode 0: the seed pass of insert_initial_seeds (:764-783); mode 1: local_growing (:899-937).
 template <int FN>
 __device__ __forceinline__ void grow_body(GrowShared &sm, NlShared *ns, const GrowDir *__restrict__ dirs, int mode, int iteration,
-                                          int wr, int max_iter_patch, int budget)
+                                          int wr, int max_iter_patch, int budget, int ntop)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char grow_heap_top[];     // ntop queue elements (dynamic LDS, host-sized)
     const GrowDir D = dirs[blockIdx.x];
+    const HeapRef heap{ (heap_ptr)D.heap, (heap_lds_ptr)(reinterpret_cast<cand4 *>(grow_heap_top)), ntop };
+    heap_top_in(heap, D.ctl->heap_size);
+    __syncthreads();
     const int t = threadIdx.x;
     const int nx = D.nx, ny = D.ny;
     const size_t pe = D.pe;
@@ -661,12 +700,12 @@ __device__ __forceinline__ void grow_body(GrowShared &sm, NlShared *ns, const Gr
                 }
             } else {
                 while (heap_size > 0) {
-                    const cand4 c = ((heap_ptr)D.heap)[0];
+                    const cand4 c = heap.ld(0);
                     const unsigned cij = __float_as_uint(c.w);
                     const int ci = (int)(cij & 0xffffu), cj = (int)(cij >> 16);
                     g = cj * nx + ci;
                     const int was_fixed = D.fixed[g];                             // in flight during the sift-down
-                    heap_remove_top_wave(D.heap, heap_size);
+                    heap_remove_top_wave(heap, heap_size);
                     ++pops;
                     if (was_fixed) continue;
                     if (t == 0) {
@@ -689,7 +728,7 @@ __device__ __forceinline__ void grow_body(GrowShared &sm, NlShared *ns, const Gr
         __syncthreads();
         if (!sm.cur[0]) { done = 1; break; }
         const int i = sm.cur[1], j = sm.cur[2];
-        add_neighbors_dev<FN>(sm, ns, D, pe, nx, ny, i, j, iteration, mode == 0 ? 1 : wr, max_iter_patch, heap_size, fills, cyc);
+        add_neighbors_dev<FN>(sm, ns, D, pe, nx, ny, i, j, iteration, mode == 0 ? 1 : wr, max_iter_patch, heap, heap_size, fills, cyc);
         if (t == 0) {
             ++solves;
             if (mode == 0) {                                                      // :778-780
@@ -700,6 +739,9 @@ __device__ __forceinline__ void grow_body(GrowShared &sm, NlShared *ns, const Gr
             }
         }
     }
+    if (t == 0) sm.cur[3] = heap_size;
+    __syncthreads();                                // (every queue operation of the first wavefront is behind its fence)
+    heap_top_out(heap, sm.cur[3]);
     if (t == 0) {
         if (!done) done = (mode == 0) ? (seed_pos >= D.nseeds) : (heap_size == 0);
         D.ctl->heap_size = heap_size;
@@ -720,17 +762,17 @@ __device__ __forceinline__ void grow_body(GrowShared &sm, NlShared *ns, const Gr
 // CU.  Measured on 256x192 pairs: 512 pairs 26.7 M windows/s with the default build, 1024 pairs 28.6 M (default)
 // vs 35.7 M (dense).  The host picks by the number of growings.
 __global__ __launch_bounds__(kPatchThreads) void grow_kernel(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr,
-                                                           int max_iter_patch, int budget)
+                                                           int max_iter_patch, int budget, int ntop)
 {
     __shared__ GrowShared sm;
-    grow_body<0>(sm, nullptr, dirs, mode, iteration, wr, max_iter_patch, budget);
+    grow_body<0>(sm, nullptr, dirs, mode, iteration, wr, max_iter_patch, budget, ntop);
 }
 
 __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void grow_kernel_dense(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr, int max_iter_patch, int budget)
+void grow_kernel_dense(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr, int max_iter_patch, int budget, int ntop)
 {
     __shared__ GrowShared sm;
-    grow_body<0>(sm, nullptr, dirs, mode, iteration, wr, max_iter_patch, budget);
+    grow_body<0>(sm, nullptr, dirs, mode, iteration, wr, max_iter_patch, budget, ntop);
 }
 
 // The same growing around the window solvers of the other functionals (grow_nl_kernels.hpp): kernels of their own, so
@@ -738,11 +780,11 @@ void grow_kernel_dense(const GrowDir *__restrict__ dirs, int mode, int iteration
 // nothing.
 template <int FN>
 __global__ __launch_bounds__(kPatchThreads) void grow_kernel_nl(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr,
-                                                              int max_iter_patch, int budget)
+                                                              int max_iter_patch, int budget, int ntop)
 {
     __shared__ GrowShared sm;
     __shared__ NlShared ns;
-    grow_body<FN>(sm, &ns, dirs, mode, iteration, wr, max_iter_patch, budget);
+    grow_body<FN>(sm, &ns, dirs, mode, iteration, wr, max_iter_patch, budget, ntop);
 }
 
 // insert_potential_candidates (src/local_faldoi.cpp:813-846) + prepare_data_for_growing (:860-870) for one growing per
@@ -761,7 +803,7 @@ __global__ __launch_bounds__(kPatchThreads) void grow_reseed_kernel(const GrowDi
             const unsigned long long fin = __builtin_amdgcn_ballot_w64(p0 + t < n && __builtin_isfinite(u) && __builtin_isfinite(v));
             for (unsigned long long rest = fin; rest != 0ull; rest &= rest - 1) {
                 const int q = __builtin_ctzll(rest), g = p0 + q;
-                if (size < D.heap_cap) heap_push_wave(D.heap, size, g % D.nx, g / D.nx, lane_read(u, q), lane_read(v, q), lane_read(e, q));
+                if (size < D.heap_cap) heap_push_wave(heap_global_only(D.heap), size, g % D.nx, g / D.nx, lane_read(u, q), lane_read(v, q), lane_read(e, q));
                 else if (t == 0) D.ctl->overflow = 1;
             }
         }
@@ -782,20 +824,23 @@ __global__ __launch_bounds__(kPatchThreads) void grow_reseed_kernel(const GrowDi
 // Test hook: replays push (1) / pop (0) operations on the device queue with one wavefront.
 __global__ __launch_bounds__(kPatchThreads) void heap_replay_kernel(Candidate *heap, int nops, const int *__restrict__ ops,
                                                                   const float *__restrict__ sims, int *__restrict__ popped,
-                                                                  int *__restrict__ npopped)
+                                                                  int *__restrict__ npopped, int ntop)
 {
-    // as in grow_body: two wavefronts, the first one runs the queue, its counters live in vector registers
+    // as in grow_body: two wavefronts, the first one runs the queue (its top `ntop` elements in LDS), its counters live in
+    // vector registers
+    extern __shared__ __attribute__((aligned(16))) unsigned char replay_heap_top[];
+    const HeapRef h{ (heap_ptr)heap, (heap_lds_ptr)(reinterpret_cast<cand4 *>(replay_heap_top)), ntop };
     if (threadIdx.x < 64) {
         int size = npopped[0], np = npopped[0];              // both 0 (the compiler cannot know)
         for (int k = 0; k < nops; ++k) {
             if (ops[k]) {
-                heap_push_wave(heap, size, k & 0xffff, (k * 7) & 0x1ff, sims[k] * 3.0f + 1.0f, -sims[k], sims[k]);
+                heap_push_wave(h, size, k & 0xffff, (k * 7) & 0x1ff, sims[k] * 3.0f + 1.0f, -sims[k], sims[k]);
             } else if (size == 0) {
                 if (threadIdx.x == 0) popped[np] = -1;
                 ++np;
             } else {
-                const cand4 c = ((heap_ptr)heap)[0];
-                heap_remove_top_wave(heap, size);
+                const cand4 c = h.ld(0);
+                heap_remove_top_wave(h, size);
                 const unsigned cw = __float_as_uint(c.w);
                 const bool intact = c.y == c.x * 3.0f + 1.0f && c.z == -c.x && (cw >> 16) == (((cw & 0xffffu) * 7) & 0x1ff);
                 if (threadIdx.x == 0) popped[np] = intact ? (int)(cw & 0xffffu) : -2;     // payload travels with its key

@@ -3,6 +3,7 @@
 path made deterministic, and the accuracy anchors against the ground truth the reference ships with its example pairs.
 Everything goes through the C ABI (ctypes releases the GIL during a call, so two Python threads are two host threads
 inside the library at the same time)."""
+import os
 import threading
 import time
 
@@ -373,3 +374,67 @@ def test_fused_nltv_kernel_equals_the_two_kernel_path_and_the_checker(ctx, oracl
             assert bits_equal(got, want), (case, w, h, mismatch_report(got, want))
             checked += 1
     assert checked >= 8
+
+
+# ------------------------------------------------------------------ the C++ batch host over RCCL (north_star: "host code stays C++")
+def _write_pairs(tmp_path, crops):
+    from PIL import Image
+    for i, c in enumerate(crops):
+        i0, i1 = sintel_pair(c)
+        for k, im in enumerate((i0, i1)):
+            Image.fromarray(im.transpose(1, 2, 0).astype(np.uint8), "RGB").save(tmp_path / ("p%d_%d.png" % (i, k)))
+
+
+def test_cpp_batch_host_over_rccl_single_rank(oracle, tmp_path):
+    """host/faldoi_batch.cpp (one process per GPU, RCCL directly: ncclBroadcast of the job table, grouped ncclSend / ncclRecv of
+    the shards, the C ABI of libfaldoi_hip.so for the work), 1 rank on the one GPU this box has -- started by itself (-gpus 1)
+    and under an external launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK, unique id through a file).  Global-only jobs
+    and pipeline jobs; every .flo bit-equal to the CPU path's."""
+    import subprocess
+    exe = F.build.build_host()["faldoi_batch"]
+    crops = [(400, 150, 160, 96), (100, 40, 160, 96), (700, 300, 160, 96)]
+    _write_pairs(tmp_path, crops)
+    lines = ["%s %s zero %s" % (tmp_path / ("p%d_0.png" % i), tmp_path / ("p%d_1.png" % i), tmp_path / ("o%d.flo" % i))
+             for i in range(len(crops))]
+    (tmp_path / "jobs.txt").write_text("\n".join(lines) + "\n")
+    want = []
+    for c in crops:
+        i0, i1 = sintel_pair(c)
+        i0n, i1n = oracle.preprocess_global(i0, i1)
+        want.append(oracle.tvl1_global(i0n, i1n, np.zeros((2, 96, 160), np.float32), warps=2, max_inner=40)[0])
+    for mode in ("self", "launcher"):
+        env = dict(os.environ)
+        cmd = [exe, str(tmp_path / "jobs.txt"), "-w", "2", "-max_inner", "40"]
+        if mode == "self":
+            cmd += ["-gpus", "1"]
+        else:
+            env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29551", FALDOI_BATCH_ID_FILE=str(tmp_path / "rccl.id"))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (mode, r.stderr[-2000:])
+        assert "3 pairs on 1 GPU(s) written" in r.stdout
+        for i in range(len(crops)):
+            got = F.flo.read_flo(str(tmp_path / ("o%d.flo" % i)))
+            assert bits_equal(got, want[i]), (mode, i)
+            os.remove(tmp_path / ("o%d.flo" % i))
+    # pipeline jobs: seed flows -> local step of the whole shard -> global step
+    from test_gpu_parity import _seed_flows
+    crops = [(400, 150, 64, 48), (100, 40, 64, 48)]
+    _write_pairs(tmp_path, crops)
+    lines, want = [], []
+    for i, c in enumerate(crops):
+        i0, i1 = sintel_pair(c)
+        a, b = oracle.preprocess_local(i0, i1)
+        go, ba = _seed_flows(oracle, a, b, 0.02, seed=70 + i)
+        F.flo.write_flo(str(tmp_path / ("s%d_0.flo" % i)), go)
+        F.flo.write_flo(str(tmp_path / ("s%d_1.flo" % i)), ba)
+        lines.append("%s %s %s %s %s" % (tmp_path / ("p%d_0.png" % i), tmp_path / ("p%d_1.png" % i), tmp_path / ("s%d_0.flo" % i),
+                                         tmp_path / ("s%d_1.flo" % i), tmp_path / ("q%d.flo" % i)))
+        local, _, _ = oracle.local_faldoi(a, b, go, ba)
+        g0, g1 = oracle.preprocess_global(i0, i1)
+        want.append(oracle.tvl1_global(g0, g1, local, warps=2, max_inner=40)[0])
+    (tmp_path / "pjobs.txt").write_text("\n".join(lines) + "\n")
+    r = subprocess.run([exe, str(tmp_path / "pjobs.txt"), "-gpus", "1", "-w", "2", "-max_inner", "40"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i in range(len(crops)):
+        assert bits_equal(F.flo.read_flo(str(tmp_path / ("q%d.flo" % i))), want[i]), i

@@ -192,3 +192,63 @@ def test_global_faldoi_parameter_file_and_occlusion_argument_form(bins, tmp_path
     assert r.returncode == 0 and r.stdout.startswith("lambda 40 ")
     r = subprocess.run([exe, str(ims), str(z), o, "one_too_many"], capture_output=True, text=True)
     assert r.returncode == 1 and "With occlusions" in r.stderr
+
+
+# ------------------------------------------------------------------ the C++ batch host: its rank logic on CPU
+def _batch_inputs(tmp_path, njobs, pipeline, rng, w=19, h=11):
+    from PIL import Image
+    lines, want = [], []
+    for j in range(njobs):
+        names = []
+        for k in range(2):
+            p = tmp_path / ("f%d_%d.png" % (j, k))
+            Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB").save(p)
+            names.append(str(p))
+        flows = []
+        for k in range(2 if pipeline else 1):
+            fl = rng.standard_normal((2, h, w)).astype(np.float32) + j
+            p = tmp_path / ("in%d_%d.flo" % (j, k))
+            F.flo.write_flo(str(p), fl)
+            flows.append(fl)
+            names.append(str(p))
+        if not pipeline and j == 1:
+            names[2] = "zero"                                   # the 2-line list-file form without an initial flow
+            flows[0] = np.zeros((2, h, w), np.float32)
+        out = tmp_path / ("out%d.flo" % j)
+        lines.append(" ".join(names + [str(out)]))
+        want.append((out, flows[0] + np.float32(1)))           # the stub solver: first flow of the job + 1
+    jobs = tmp_path / "jobs.txt"
+    jobs.write_text("# a comment line\n" + "\n".join(lines) + "\n")
+    return jobs, want
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 3])
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_batch_host_rank_logic_with_stub_communicator(bins, tmp_path, gpus, pipeline):
+    """faldoi_batch (host/faldoi_batch.cpp) built with -DFALDOI_BATCH_STUB: the same source with pipes in place of RCCL and
+    `flow + 1` in place of the solver.  Job table broadcast, round-robin shards with a ragged last round (5 jobs on 1 / 2 / 3
+    ranks), padded scatter, gather, job -> output file mapping, both job forms."""
+    rng = np.random.default_rng(10 * gpus + int(pipeline))
+    jobs, want = _batch_inputs(tmp_path, 5, pipeline, rng)
+    r = subprocess.run([bins["faldoi_batch_stub"], str(jobs), "-gpus", str(gpus)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "5 pairs on %d GPU(s) written" % gpus in r.stdout
+    for path, flow in want:
+        got = F.flo.read_flo(str(path))
+        assert np.array_equal(got.view(np.uint32), flow.view(np.uint32)), path
+
+
+def test_batch_host_failures_reach_every_rank(bins, tmp_path):
+    """Rank 0 cannot read an input: every rank learns it from the header broadcast and leaves with exit code 3 (nobody is
+    left waiting in a collective); bad job tables and usage errors are reported as such."""
+    rng = np.random.default_rng(3)
+    jobs, _ = _batch_inputs(tmp_path, 3, False, rng)
+    text = jobs.read_text().replace("f1_0.png", "missing.png")
+    jobs.write_text(text)
+    r = subprocess.run([bins["faldoi_batch_stub"], str(jobs), "-gpus", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "cannot read the jobs" in r.stderr
+    (tmp_path / "mixed.txt").write_text("a b c d\na b c d e\n")
+    r = subprocess.run([bins["faldoi_batch_stub"], str(tmp_path / "mixed.txt"), "-gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "cannot be mixed" in r.stderr
+    r = subprocess.run([bins["faldoi_batch_stub"]], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "usage" in r.stderr
