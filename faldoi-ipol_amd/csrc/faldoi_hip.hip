@@ -314,6 +314,8 @@ extern "C" int faldoi_ctx_persist_retry(faldoi_ctx *c)
 static float *plane_ptr(faldoi_tvl1_batch *b, int pair, int plane);
 static int prim_check(faldoi_ctx *ctx, int nx, int ny);
 
+#include "tvl1_probe_host.inc"
+
 // ------------------------------------------------------------------------------------------ tiling
 struct TileCfg {
     int R, NW;           // rows per thread, waves per workgroup (tile = 64 x R*NW)
@@ -853,72 +855,8 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         ++c->persist_launches;
         c->persist_backoff_len = 0;
     }
-    if (p_stamps_out) {
-        std::vector<unsigned long long> hs((size_t)kPersistStamps * ntiles);
-        HIP_TRY(hipMemcpy(hs.data(), p_stamps_out, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
-        // stamp slots: 0 warp start | 7 a middle wave's ring stores drained | 2 barrier passed, flag stored | 3 neighbours ready |
-        // 4 halo landed | 5 first chunk iterated | 12, 8, 9, 10, 11 the same for the last exchange of the warp | 6 warp done
-        static const int order[] = { 0, 1, 7, 2, 3, 4, 5, 12, 8, 9, 10, 11, 6 };
-        static const char *name[] = { "", "warp constants", "ring stored and drained", "barrier, flag", "neighbours ready", "halo landed",
-                                      "chunk iterated", "ring stored and drained", "barrier, flag", "neighbours ready", "halo landed",
-                                      "chunk iterated", "(end of warp)" };
-        fprintf(stderr, "faldoi persistent stamps, warp %d, %d tiles; us since the previous stamp, mean / max over the tiles:\n", warps / 2, ntiles);
-        for (int j = 1; j < 13; ++j) {
-            double sum = 0, mx = 0;
-            int cnt = 0;
-            for (int q = 0; q < ntiles; ++q) {
-                const unsigned long long t1 = hs[(size_t)kPersistStamps * q + order[j]], t0 = hs[(size_t)kPersistStamps * q + order[j - 1]];
-                if (!t1 || !t0) continue;
-                const double us = ((double)t1 - (double)t0) * 0.01;
-                sum += us;
-                if (us > mx) mx = us;
-                ++cnt;
-            }
-            if (cnt) fprintf(stderr, "   %-42s %6.2f / %6.2f\n", name[j], sum / cnt, mx);
-        }
-        {
-            double cyc = 0, ref = 0;                                     // shader clock (s_memtime) against the constant 100 MHz clock
-            for (int q = 0; q < ntiles; ++q) {
-                const unsigned long long *v = &hs[(size_t)kPersistStamps * q];
-                if (v[14] > v[13] && v[6] > v[0]) { cyc += (double)(v[14] - v[13]); ref += (double)(v[6] - v[0]); }
-            }
-            if (ref > 0) fprintf(stderr, "   shader clock during that warp: %.0f MHz\n", cyc / ref * 100.0);
-        }
-        if (atoi(getenv("FALDOI_STAMPS")) > 1) {                      // per tile: warp constants | both chunks' iterations | whole warp
-            for (int pass = 0; pass < 3; ++pass) {
-                fprintf(stderr, "%s\n", pass == 0 ? "warp constants (us), tile grid:" : pass == 1 ? "iterations of the warp (us):" : "whole warp (us):");
-                for (int ty = 0; ty < nty; ++ty) {
-                    for (int tx = 0; tx < ntx; ++tx) {
-                        const unsigned long long *q = &hs[(size_t)kPersistStamps * (ty * ntx + tx)];
-                        const double v = pass == 0 ? (double)(q[1] - q[0]) : pass == 1 ? (double)(q[5] - q[4]) + (double)(q[11] - q[10]) : (double)(q[6] - q[0]);
-                        fprintf(stderr, "%5.1f", v * 0.01);
-                    }
-                    fprintf(stderr, "\n");
-                }
-            }
-        }
-    }
-    if (d_stamps) {
-        std::vector<unsigned long long> hs((size_t)4 * total_tiles);
-        HIP_TRY(hipMemcpy(hs.data(), d_stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull, tend = 0;
-        for (int q = 0; q < total_tiles; ++q) { if (hs[4 * q] && hs[4 * q] < t0) t0 = hs[4 * q]; if (hs[4 * q + 3] > tend) tend = hs[4 * q + 3]; }
-        double sum[4] = { 0, 0, 0, 0 }, mx[4] = { 0, 0, 0, 0 };
-        for (int q = 0; q < total_tiles; ++q)
-            for (int c = 0; c < 4; ++c) {
-                const double us = (double)(hs[4 * q + c] - t0) * 0.01;
-                sum[c] += us;
-                if (us > mx[c]) mx[c] = us;
-            }
-        if (atoi(getenv("FALDOI_STAMPS")) > 1)                       // the iteration phase of every tile, as a grid
-            for (int ty = 0; ty < nty; ++ty) {
-                for (int tx = 0; tx < ntx; ++tx) fprintf(stderr, "%5.1f", (double)(hs[4 * (ty * ntx + tx) + 2] - hs[4 * (ty * ntx + tx) + 1]) * 0.01);
-                fprintf(stderr, "\n");
-            }
-        fprintf(stderr, "faldoi stamps (us after the first workgroup started; mean / max over %d workgroups): start %.2f / %.2f, loads landed "
-                        "%.2f / %.2f, iterations done %.2f / %.2f, stores drained %.2f / %.2f\n", total_tiles, sum[0] / total_tiles, mx[0],
-                sum[1] / total_tiles, mx[1], sum[2] / total_tiles, mx[2], sum[3] / total_tiles, mx[3]);
-    }
+    if (p_stamps_out) { const int rc = probe_report_persistent(p_stamps_out, ntiles, ntx, nty, warps); if (rc) return rc; }   // tvl1_probe_host.inc
+    if (d_stamps) { const int rc = probe_report_chunk(d_stamps, total_tiles, ntx, nty); if (rc) return rc; }
     std::vector<int> h_it((size_t)warps * b->npairs);
     std::vector<float> h_er((size_t)warps * b->npairs);
     HIP_TRY(hipMemcpy(h_it.data(), b->d_iters, sizeof(int) * h_it.size(), hipMemcpyDeviceToHost));

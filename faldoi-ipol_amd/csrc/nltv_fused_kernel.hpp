@@ -84,6 +84,32 @@ __device__ __forceinline__ float nl_dual_update(float p0, float w, float a, floa
     const float d = 1 + tau * ag;
     return (p0 + tau * g) / d;
 }
+// The same for N slots at once with ONE range test (on the largest |g|): a wave alone on its SIMD pays every branch with idle issue
+// slots, and the test is never true on real data.
+template <int N>
+__device__ __forceinline__ void nl_dual_update_n(float (&p)[N], const float (&w)[N], float a, const float (&n)[N], float wt, double rwt,
+                                                 float tau)
+{
+    float g[N], ag[N];
+    unsigned top = 0u;                                                // largest |g| as an integer: NaN and infinity order above every finite value
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        g[q] = (kNfWhatIf & 4) ? w[q] * (a - n[q]) * wt : div_by(w[q] * (a - n[q]), wt, rwt);
+        const unsigned ab = __float_as_uint(g[q]) & 0x7fffffffu;
+        ag[q] = __uint_as_float(ab);
+        top = ab > top ? ab : top;
+    }
+    if (__builtin_amdgcn_ballot_w64(top > 0x5d800000u /* 2^60 */) != 0ull) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < N; ++q) ag[q] = __builtin_sqrtf(g[q] * g[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const float d = 1 + tau * ag[q];
+        p[q] = (kNfWhatIf & 4) ? p[q] + g[q] : (p[q] + tau * g[q]) / d;
+    }
+}
 
 // Offsets of slot s in the 5x5 raster (rows first, centre skipped)
 __device__ __forceinline__ constexpr int nl_slot_k(int s) { return (s < 12 ? s : s + 1) / 5 - kNlR; }
@@ -202,15 +228,23 @@ __device__ __forceinline__ void nf_dual_own(NfLds<TY> &L, const NfArgs &a, NfRsr
                 oks[s] = !BORDER || (x + l >= 0 && x + l < a.nx && y + k >= 0 && y + k < a.ny);
             }
         }
+        // (a slot that leaves the image is evaluated like the others -- its weight and its neighbour's ubar read as 0 -- but never
+        // stored: such slots keep their duals, :1145, and the divergence skips them)
+        float pb6[kNlBatch], wb6[kNlBatch], nb6[kNlBatch];
 #pragma unroll
-        for (int s = s0; s < s0 + kNlBatch; ++s) {
-            const int k = nl_slot_k(s), l = nl_slot_l(s);
-            if (!BORDER || oks[s]) {                               // slots that leave the image keep their duals (never written, :1145)
-                const float pn = nl_dual_update(preg[s], wreg[s], ai, L.ub[COMP][ly + kNlR + k][lx + kNlR + l], wt, rwt, a.tau);
-                if (!(kNfWhatIf & 16)) nf_st(rs, (unsigned)(d_new + s) * pb, i4, pn);
-                L.pq[s][ly + kNlR][lx + kNlR] = pn;
-                preg[s] = pn;
-            }
+        for (int q = 0; q < kNlBatch; ++q) {
+            const int s = s0 + q;
+            pb6[q] = preg[s];
+            wb6[q] = wreg[s];
+            nb6[q] = L.ub[COMP][ly + kNlR + nl_slot_k(s)][lx + kNlR + nl_slot_l(s)];
+        }
+        nl_dual_update_n<kNlBatch>(pb6, wb6, ai, nb6, wt, rwt, a.tau);
+#pragma unroll
+        for (int q = 0; q < kNlBatch; ++q) {
+            const int s = s0 + q;
+            if (!(kNfWhatIf & 16) && (!BORDER || oks[s])) nf_st(rs, (unsigned)(d_new + s) * pb, i4, pb6[q]);
+            L.pq[s][ly + kNlR][lx + kNlR] = pb6[q];
+            preg[s] = pb6[q];
         }
     }
 }
@@ -365,9 +399,28 @@ __global__ __launch_bounds__(kNfW * TY) void nl_fused_kernel(NfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char nf_lds_raw[];
     NfLds<TY> &L = *reinterpret_cast<NfLds<TY> *>(nf_lds_raw);
-    const int per = gridDim.x >> 3;                                // XCD-aware tile order (blocks are dealt to the 8 XCDs round-robin)
-    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= a.ntx * a.nty) return;
+    // XCD-aware tile order: blocks are dealt to the 8 XCDs round-robin, so XCD k gets the `per` consecutive tiles [k per, (k+1) per)
+    // (neighbouring tiles re-read each other's ring from one L2), block j of the XCD takes the j-th of them.  Among those the tiles on
+    // the image frame go FIRST: they are the slower ones (stencil validity selects), and the grid runs in rounds of one tile per CU --
+    // a slow tile in the last round is what the whole launch waits for.
+    const int per = gridDim.x >> 3, ntiles = a.ntx * a.nty;
+    const int k = blockIdx.x & 7, j = blockIdx.x >> 3;
+    int tile = k * per + j;
+    if (per <= 64) {
+        const int lane = threadIdx.x & 63;
+        const int tq = k * per + lane;                                 // lane q looks at the q-th tile of this XCD
+        const bool valid = lane < per && tq < ntiles;
+        const int qy = tq / a.ntx, qx = tq - qy * a.ntx;
+        const bool inner = qx * kNfW >= kCsR && qy * TY >= kCsR && qx * kNfW + kNfW + kCsR <= a.nx && qy * TY + TY + kCsR <= a.ny;
+        const unsigned long long frame = __builtin_amdgcn_ballot_w64(valid && !inner), rest = __builtin_amdgcn_ballot_w64(valid && inner);
+        const int nframe = __builtin_popcountll(frame);
+        const unsigned long long from = j < nframe ? frame : rest;
+        const int want = j < nframe ? j : j - nframe;                  // the want-th set bit of `from`
+        const int rank = __builtin_popcountll(from & ((1ull << lane) - 1ull));
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(((from >> lane) & 1ull) != 0ull && rank == want);
+        tile = hit ? k * per + __builtin_ctzll(hit) : ntiles;          // (no such tile: this block has nothing to do)
+    }
+    if (tile >= ntiles) return;
     const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
     const int X0 = txi * kNfW, Y0 = tyi * TY;
     const bool interior = X0 >= kCsR && Y0 >= kCsR && X0 + kNfW + kCsR <= a.nx && Y0 + TY + kCsR <= a.ny;

@@ -132,14 +132,20 @@ def case_tvcsad(rng):
 
 
 def case_nltv(rng):
-    w, h = int(rng.integers(8, 90)), int(rng.integers(8, 70))
+    # (sizes up to five tile columns of the fused kernel and several tile rows; every tile height the host can pick)
+    w, h = (int(rng.integers(8, 90)), int(rng.integers(8, 70))) if rng.random() < 0.5 else (int(rng.integers(60, 330)), int(rng.integers(12, 120)))
+    rows = rng.choice(["", "8", "12", "14", "16"])
+    if rows:
+        os.environ["FALDOI_NL_ROWS"] = str(rows)
+    else:
+        os.environ.pop("FALDOI_NL_ROWS", None)
     (c0, c1), cr = crop_pair(rng, w, h)
     i0n, i1n = O.preprocess_global(c0, c1)
     lab = O.image_to_lab(c0)
     u0 = (rng.normal(0, float(rng.choice([0, 0.5])), (2, h, w))).astype(np.float32)
-    prm = dict(warps=int(rng.integers(1, 3)), max_inner=int(rng.integers(1, 40)))
+    prm = dict(warps=int(rng.integers(1, 3)), max_inner=int(rng.integers(1, 40 if w * h < 8000 else 10)))
     l1 = rng.random() < 0.4
-    desc = "crop %s %s %s" % (cr, prm, "NLTV-L1" if l1 else "NLTV-CSAD")
+    desc = "crop %s %s %s rows %s" % (cr, prm, "NLTV-L1" if l1 else "NLTV-CSAD", rows or "auto")
     if l1:
         want = O.nltvl1_global(i0n, i1n, lab, u0, **prm)
         got = ctx.nltvl1_global(i0n, i1n, lab, u0, **prm)
