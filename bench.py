@@ -223,10 +223,10 @@ def main():
     # Parity evidence of every rank's own result (outside the timed region; world > 1 only -- alone, rank 0's full comparison
     # below covers it): a 48-bit checksum of the flow the timed steps left behind, and a bounded comparison with the CPU checker.
     per_rank_check = None
-    if world > 1:
+    if world > 1 or os.environ.get("FALDOI_BENCH_RANK_CHECK"):       # (the variable: rehearsal of the N > 1 code on a one-GPU box)
         crc, same = rank_check(F, np, batch, pairs, step, args.no_cpu_baseline)
-        crcs = F.shard.gather_scalars(crc, dist, dev)
-        sames = F.shard.gather_scalars(same, dist, dev)
+        crcs = F.shard.gather_scalars(crc, dist if use_dist else None, dev)
+        sames = F.shard.gather_scalars(same, dist if use_dist else None, dev)
         per_rank_check = [{"rank": r, "flow_sha256_48": "%012x" % int(c), "bit_identical_to_cpu_first_%d_warps" % CHECK_WARPS:
                            (None if v < 0 else bool(v))} for r, (c, v) in enumerate(zip(crcs, sames))]
 

@@ -1412,8 +1412,7 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const size_t n = (size_t)nx * ny, nb = n * sizeof(float);
-    size_t pe = ((n + 63) / 64) * 64;
-    if (const char *v = getenv("FALDOI_NL_PAD")) pe += 64 * (size_t)atoi(v);      // tuning aid: plane stride in units of 256 B
+    const size_t pe = ((n + 63) / 64) * 64;     // (padding the plane stride by odd multiples of 256 B was measured: no effect)
 
     // host tables (threads over row bands)
     std::vector<float> wts((size_t)kNlSlots * n), wt(n);
