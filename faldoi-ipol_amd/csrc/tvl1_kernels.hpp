@@ -301,11 +301,16 @@ struct TileState {
 // below and by the persistent kernel (tvl1_persist_kernel.hpp).  halo_y = rows of halo above and below the owned rows; the
 // caller has put row 0 of every wave's ubar into s_ub1 / s_ub2 and zeroed s_err[0..iters).  Per-lane maxima of |du|^2 over
 // the owned pixels are left in s_err[it][lane].
-template <int R, int NW, int BORDER>
+struct TvNoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// `after_duals(it)`: called by every thread of a computing wave once the duals of iteration `it` are final (before the barrier that
+// precedes the primal step) -- the persistent kernel publishes the ring's duals from there in the last iteration of a chunk.
+template <int R, int NW, int BORDER, typename Hook = TvNoHook>
 __device__ __forceinline__ void tvl1_iterate(TileState<R> &s, int iters, int halo_y, int gx, int gy0, int nx, int ny,
                                              int lane, int wv, bool wave_live, const TvConst &prm,
                                              float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
-                                             float (*s_x22)[kTileW], unsigned (*s_err)[kTileW])
+                                             float (*s_x22)[kTileW], unsigned (*s_err)[kTileW], Hook after_duals = Hook())
 {
     constexpr int TH = R * NW;
     // BORDER bit 0: the tile footprint contains image column 0 or nx-1; bit 1: row 0 or ny-1.  A tile on the left or right
@@ -344,6 +349,7 @@ __device__ __forceinline__ void tvl1_iterate(TileState<R> &s, int iters, int hal
             }
             s_x12[wv][lane] = s.x12[R - 1];
             s_x22[wv][lane] = s.x22[R - 1];
+            after_duals(it);
         }
         if (!(kWhatIf & 1)) __syncthreads();                   // new duals' last rows visible
         // ---- primal step: divergence (:745-746), TH (:690-718), getP (:770), relax (:780) ----

@@ -33,6 +33,10 @@ namespace faldoi {
 constexpr int kXPlanes = 11;       // exchange slots: u1 u2 ub1 ub2 xi11 xi12 xi21 xi22 rho_c I1wx I1wy
 constexpr int kFlagStride = 32;    // unsigned words between two tiles' flags: one 128-B line each
 constexpr int kPersistStamps = 16;  // stamps per tile (measurement aid)
+#ifndef FALDOI_PERSIST_EARLY_DUALS
+#define FALDOI_PERSIST_EARLY_DUALS 1
+#endif
+constexpr bool kPersistEarlyDuals = FALDOI_PERSIST_EARLY_DUALS != 0;
 
 typedef unsigned int xvec4 __attribute__((ext_vector_type(4)));
 
@@ -192,7 +196,17 @@ __device__ __forceinline__ void px_warp_constants(TileState<R> &s, const float *
 // Publish: write-through, one 16-byte vector (the thread's R rows) per plane.  `first`: the exchange at a warp's start carries the
 // warp constants and no ubar (ubar = u there, :659-660).  Called by the threads of the ring only.
 template <int R, typename RSRC>
-__device__ __forceinline__ void px_publish(const TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride, bool first)
+__device__ __forceinline__ void px_publish_duals(const TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x11), rsrc, base + 4u * plane_stride, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x12), rsrc, base + 5u * plane_stride, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x21), rsrc, base + 6u * plane_stride, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x22), rsrc, base + 7u * plane_stride, 0, 16);
+}
+// `duals`: false when px_publish_duals has stored them already (from inside the previous chunk's last iteration)
+template <int R, typename RSRC>
+__device__ __forceinline__ void px_publish(const TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride, bool first,
+                                           bool duals = true)
 {
     __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u1), rsrc, base + 0u * plane_stride, 0, 16);
     __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u2), rsrc, base + 1u * plane_stride, 0, 16);
@@ -200,10 +214,7 @@ __device__ __forceinline__ void px_publish(const TileState<R> &s, RSRC rsrc, uns
         __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub1), rsrc, base + 2u * plane_stride, 0, 16);
         __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub2), rsrc, base + 3u * plane_stride, 0, 16);
     }
-    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x11), rsrc, base + 4u * plane_stride, 0, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x12), rsrc, base + 5u * plane_stride, 0, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x21), rsrc, base + 6u * plane_stride, 0, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x22), rsrc, base + 7u * plane_stride, 0, 16);
+    if (duals) px_publish_duals<R>(s, rsrc, base, plane_stride);
     if (first) {
         __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.rc), rsrc, base + 8u * plane_stride, 0, 16);
         __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ix), rsrc, base + 9u * plane_stride, 0, 16);
@@ -346,7 +357,11 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             ++epoch;
             const unsigned par = (epoch & 1u) * parity_stride;
 
-            if (ring) px_publish<R>(s, rsrc, par + pub_off, plane_stride, first);
+            // (the ring's duals of every exchange but the first of the launch went out from inside the previous chunk's last iteration:
+            // they are final after its dual step, and half of the exchange's bytes drain while the primal step computes)
+            // (publishing the flow early as well at a warp's end -- it then drains during the warp constants -- was measured: no
+            // further gain, 11.93 against 11.90 ms: the exchange at a warp's start waits for the owners' bicubic phase, not for bytes)
+            if (ring) px_publish<R>(s, rsrc, par + pub_off, plane_stride, first, !(kPersistEarlyDuals && epoch > 1));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the barrier
             if (a.stamps && w == a.stamp_warp && threadIdx.x == 64 * (NW / 2)) st[first ? 7 : 12] = __builtin_amdgcn_s_memrealtime();
             __syncthreads();
@@ -374,8 +389,15 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             s_ub2[wv][lane] = s.ub2[0];
 
             const bool ends_warp = n + it >= a.prm.max_inner;
+            // the slab the NEXT exchange uses (other parity): every neighbour has finished reading it -- it needed this tile's
+            // flag of the CURRENT exchange to get where it is, and raised its own only after its previous fetch
+            const bool more = !(ends_warp && w == a.prm.warps - 1);
+            const unsigned par_next = ((epoch + 1u) & 1u) * parity_stride;
+            auto early_duals = [&](int iter) {
+                if (kPersistEarlyDuals && more && ring && iter == it - 1) px_publish_duals<R>(s, rsrc, par_next + pub_off, plane_stride);
+            };
             tvl1_iterate<R, NW, BORDER>(s, it, a.hy, gx, gy0, nx, ny, lane, wv, wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
-                                        s_err);
+                                        s_err, early_duals);
             if (stamp) st[first ? 5 : 11] = __builtin_amdgcn_s_memrealtime();
 
             __syncthreads();                                       // the last iteration's maxima are in s_err
