@@ -306,11 +306,13 @@ struct TvNoHook {
 };
 // `after_duals(it)`: called by every thread of a computing wave once the duals of iteration `it` are final (before the barrier that
 // precedes the primal step) -- the persistent kernel publishes the ring's duals from there in the last iteration of a chunk.
-template <int R, int NW, int BORDER, typename Hook = TvNoHook>
+// `after_primal(it)`: the same once flow and ubar of iteration `it` are final.
+template <int R, int NW, int BORDER, typename Hook = TvNoHook, typename Hook2 = TvNoHook>
 __device__ __forceinline__ void tvl1_iterate(TileState<R> &s, int iters, int halo_y, int gx, int gy0, int nx, int ny,
                                              int lane, int wv, bool wave_live, const TvConst &prm,
                                              float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
-                                             float (*s_x22)[kTileW], unsigned (*s_err)[kTileW], Hook after_duals = Hook())
+                                             float (*s_x22)[kTileW], unsigned (*s_err)[kTileW], Hook after_duals = Hook(),
+                                             Hook2 after_primal = Hook2())
 {
     constexpr int TH = R * NW;
     // BORDER bit 0: the tile footprint contains image column 0 or nx-1; bit 1: row 0 or ny-1.  A tile on the left or right
@@ -385,6 +387,7 @@ __device__ __forceinline__ void tvl1_iterate(TileState<R> &s, int iters, int hal
             // per-lane running maximum of this iteration (values >= 0: uint order == float order;
             // max is order-independent => deterministic); reduced across lanes once, at the end
             atomicMax(&s_err[it][lane], __float_as_uint(emax));
+            after_primal(it);
         }
     }
 }

@@ -37,6 +37,10 @@ constexpr int kPersistStamps = 16;  // stamps per tile (measurement aid)
 #define FALDOI_PERSIST_EARLY_DUALS 1
 #endif
 constexpr bool kPersistEarlyDuals = FALDOI_PERSIST_EARLY_DUALS != 0;
+#ifndef FALDOI_PERSIST_EARLY_FLOW
+#define FALDOI_PERSIST_EARLY_FLOW 1
+#endif
+constexpr bool kPersistEarlyFlow = kPersistEarlyDuals && FALDOI_PERSIST_EARLY_FLOW != 0;
 
 typedef unsigned int xvec4 __attribute__((ext_vector_type(4)));
 
@@ -203,14 +207,24 @@ __device__ __forceinline__ void px_publish_duals(const TileState<R> &s, RSRC rsr
     __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x21), rsrc, base + 6u * plane_stride, 0, 16);
     __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.x22), rsrc, base + 7u * plane_stride, 0, 16);
 }
-// `duals`: false when px_publish_duals has stored them already (from inside the previous chunk's last iteration)
 template <int R, typename RSRC>
-__device__ __forceinline__ void px_publish(const TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride, bool first,
-                                           bool duals = true)
+__device__ __forceinline__ void px_publish_flow(const TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride)
 {
     __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u1), rsrc, base + 0u * plane_stride, 0, 16);
     __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u2), rsrc, base + 1u * plane_stride, 0, 16);
-    if (!first) {
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub1), rsrc, base + 2u * plane_stride, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub2), rsrc, base + 3u * plane_stride, 0, 16);
+}
+// `duals` / `flow`: false when px_publish_duals / px_publish_flow has stored them already (from inside the previous chunk's last iteration)
+template <int R, typename RSRC>
+__device__ __forceinline__ void px_publish(const TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride, bool first,
+                                           bool duals = true, bool flow = true)
+{
+    if (flow) {
+        __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u1), rsrc, base + 0u * plane_stride, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.u2), rsrc, base + 1u * plane_stride, 0, 16);
+    }
+    if (flow && !first) {
         __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub1), rsrc, base + 2u * plane_stride, 0, 16);
         __builtin_amdgcn_raw_buffer_store_b128(pack_rows<R>(s.ub2), rsrc, base + 3u * plane_stride, 0, 16);
     }
@@ -361,7 +375,8 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             // they are final after its dual step, and half of the exchange's bytes drain while the primal step computes)
             // (publishing the flow early as well at a warp's end -- it then drains during the warp constants -- was measured: no
             // further gain, 11.93 against 11.90 ms: the exchange at a warp's start waits for the owners' bicubic phase, not for bytes)
-            if (ring) px_publish<R>(s, rsrc, par + pub_off, plane_stride, first, !(kPersistEarlyDuals && epoch > 1));
+            if (ring) px_publish<R>(s, rsrc, par + pub_off, plane_stride, first, !(kPersistEarlyDuals && epoch > 1),
+                                    !(kPersistEarlyFlow && !first));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the barrier
             if (a.stamps && w == a.stamp_warp && threadIdx.x == 64 * (NW / 2)) st[first ? 7 : 12] = __builtin_amdgcn_s_memrealtime();
             __syncthreads();
@@ -396,8 +411,13 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             auto early_duals = [&](int iter) {
                 if (kPersistEarlyDuals && more && ring && iter == it - 1) px_publish_duals<R>(s, rsrc, par_next + pub_off, plane_stride);
             };
+            // and in a chunk that does not end its warp, flow and ubar go the same way once the last iteration's primal step is done:
+            // before the workgroup's end-of-chunk barrier instead of behind it
+            auto early_flow = [&](int iter) {
+                if (kPersistEarlyFlow && !ends_warp && ring && iter == it - 1) px_publish_flow<R>(s, rsrc, par_next + pub_off, plane_stride);
+            };
             tvl1_iterate<R, NW, BORDER>(s, it, a.hy, gx, gy0, nx, ny, lane, wv, wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
-                                        s_err, early_duals);
+                                        s_err, early_duals, early_flow);
             if (stamp) st[first ? 5 : 11] = __builtin_amdgcn_s_memrealtime();
 
             __syncthreads();                                       // the last iteration's maxima are in s_err
