@@ -117,6 +117,8 @@ struct faldoi_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int *h_done = nullptr;            // pinned
+    int *h_stats = nullptr;           // pinned staging of a solve's per-warp iteration counts and errors (one copy queued behind the
+    size_t h_stats_cap = 0;           // solve, one synchronisation for everything), in ints
     int n_cu = 256;
     // What this context has seen of the persistent TV-L1 kernel (tvl1_persist_kernel.hpp), faldoi_ctx_persist_stats:
     long persist_launches = 0;        // solves that ran as one persistent launch
@@ -282,6 +284,7 @@ extern "C" void faldoi_ctx_destroy(faldoi_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->h_done) (void)hipHostFree(c->h_done);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
     delete c;
 }
 
@@ -827,7 +830,18 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         for (int i = 0; i < b->npairs; ++i) b->final_cur[i] = hc[i].cur;
     }
     HIP_TRY(hipEventRecord(c->ev1, s));
-    HIP_TRY(hipEventSynchronize(c->ev1));
+    // the per-warp iteration counts and errors follow the solve down the same stream into pinned memory: one wait for everything
+    const size_t nstat = (size_t)warps * b->npairs;
+    if (c->h_stats_cap < 2 * nstat) {
+        if (c->h_stats) (void)hipHostFree(c->h_stats);
+        c->h_stats = nullptr;
+        c->h_stats_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&c->h_stats, sizeof(int) * 2 * nstat, hipHostMallocDefault));
+        c->h_stats_cap = 2 * nstat;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_stats, b->d_iters, sizeof(int) * nstat, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_stats + nstat, b->d_err, sizeof(float) * nstat, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     double chunk_ms = 0.0;
@@ -857,10 +871,8 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     }
     if (p_stamps_out) { const int rc = probe_report_persistent(p_stamps_out, ntiles, ntx, nty, warps); if (rc) return rc; }   // tvl1_probe_host.inc
     if (d_stamps) { const int rc = probe_report_chunk(d_stamps, total_tiles, ntx, nty); if (rc) return rc; }
-    std::vector<int> h_it((size_t)warps * b->npairs);
-    std::vector<float> h_er((size_t)warps * b->npairs);
-    HIP_TRY(hipMemcpy(h_it.data(), b->d_iters, sizeof(int) * h_it.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h_er.data(), b->d_err, sizeof(float) * h_er.size(), hipMemcpyDeviceToHost));
+    const int *h_it = c->h_stats;
+    const float *h_er = reinterpret_cast<const float *>(c->h_stats + nstat);
     long px_iters = 0;
     for (int i = 0; i < b->npairs; ++i) {
         long tot = 0;
