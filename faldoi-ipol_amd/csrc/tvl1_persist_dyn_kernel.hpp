@@ -91,8 +91,21 @@ __device__ __forceinline__ void tvl1_persist_dyn_body(const PersistArgs &a, int 
             }
             s_ub1[wv][lane] = s.ub1[0];
             s_ub2[wv][lane] = s.ub2[0];
+            // The ring leaves from inside the chunk's last iteration, as in the static kernel (tvl1_persist_kernel.hpp): the duals
+            // after its dual step, flow and ubar after its primal step, into the slab of the exchange that follows (every neighbour
+            // is done reading that slab: it published the current exchange only after its previous fetch).  Published on the
+            // assumption that the warp goes on, like the whole ring before; if the stop test ends the warp instead -- also after an
+            // exact-length re-run, which publishes nothing -- nobody fetches it, and the next warp's first exchange writes every
+            // plane it reads into the other slab.
+            const unsigned par_next = ((epoch + 1u) & 1u) * g.parity_stride;
+            auto early_duals = [&](int iter) {
+                if (kPersistEarlyDuals && g.ring && iter == it - 1) px_publish_duals<R>(s, rsrc, par_next + g.pub_off, g.plane_stride);
+            };
+            auto early_flow = [&](int iter) {
+                if (kPersistEarlyDuals && g.ring && iter == it - 1) px_publish_flow<R>(s, rsrc, par_next + g.pub_off, g.plane_stride);
+            };
             tvl1_iterate<R, NW, BORDER>(s, it, a.hy, g.gx, g.gy0, nx, ny, lane, wv, g.wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
-                                        s_err);
+                                        s_err, early_duals, early_flow);
             __syncthreads();                                       // every iteration's per-lane maxima are in s_err
 
             // ---- publish the ring and this chunk's tile maxima; wait for every tile ----
@@ -113,7 +126,7 @@ __device__ __forceinline__ void tvl1_persist_dyn_body(const PersistArgs &a, int 
                 if (lane == 0) __hip_atomic_store(board + (size_t)t * kMaxChunk + i, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_err[i][lane] = 0u;
             }
-            if (g.ring) px_publish<R>(s, rsrc, par + g.pub_off, g.plane_stride, false);
+            if (g.ring && !kPersistEarlyDuals) px_publish<R>(s, rsrc, par + g.pub_off, g.plane_stride, false);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ring and board entries drained by every storing wave
             __syncthreads();
             if (tid == 0) __hip_atomic_store(a.flags + (size_t)t * kFlagStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
