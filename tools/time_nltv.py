@@ -7,8 +7,9 @@ from util import sintel_pair
 ctx = F.Context(0); i0, i1 = sintel_pair()
 i0n, i1n = ctx.preprocess_global(i0, i1)
 t = time.perf_counter(); lab = F.capi.image_to_lab(i0); print("lab host %.1f ms" % ((time.perf_counter() - t) * 1e3))
+l1 = os.environ.get("NLTV_L1") == "1"            # NLTV-L1 (the same regulariser, TV-L1's data term) instead of NLTV-CSAD
 for _ in range(2):
     t = time.perf_counter()
-    u, ms = ctx.nltvcsad_global(i0n, i1n, lab, np.zeros((2, 436, 1024), np.float32), warps=1, max_inner=400)
-    print("NLTV-CSAD 1024x436, 1 warp x 400 its: device %.2f ms (%.1f us/iter, %.2f Gpx*it/s), wall %.1f ms"
+    u, ms = (ctx.nltvl1_global if l1 else ctx.nltvcsad_global)(i0n, i1n, lab, np.zeros((2, 436, 1024), np.float32), warps=1, max_inner=400)
+    print(("NLTV-L1 " if l1 else "NLTV-CSAD") + " 1024x436, 1 warp x 400 its: device %.2f ms (%.1f us/iter, %.2f Gpx*it/s), wall %.1f ms"
           % (ms, ms * 1e3 / 400, 1024 * 436 * 400 / ms / 1e6, (time.perf_counter() - t) * 1e3))
