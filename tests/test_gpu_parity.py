@@ -1107,6 +1107,14 @@ def test_full_size_pipeline_final_hard_reference_defaults(ctx, oracle, tmp_path)
     got = F.flo.read_flo(str(tmp_path / "out.flo"))
     assert float(F.flo.epe(got, u).mean()) <= EPE_GATE
     assert bits_equal(got, u), mismatch_report(got, u)
+    # accuracy anchor: the ground truth the reference ships for this pair (example_data/final/hard/gt, committed fixture).  With
+    # these matcher-free seeds (1.1 % of a dense TV-L1 flow of a 39-px-motion pair) the chain lands at ~24.6 px -- between the zero
+    # flow's 31.99 and what real matches would give; the bound catches a broken chain, the bits above catch everything else
+    gt = np.load(GOLDEN + "/sintel_final_hard_gt_frame_0002.npz")["gt"]
+    epe_gt = float(F.flo.epe(got, gt).mean())
+    assert abs(float(F.flo.epe(np.zeros_like(gt), gt).mean()) - 31.9898) < 1e-3
+    assert 20.0 < epe_gt < 28.0, epe_gt
+    print("configs[2] 1024x436 -split_img 0: EPE vs ground truth %.4f px (zero flow 31.99)" % epe_gt)
     print("configs[2] 1024x436 -split_img 0: faldoi_flow %.1f s wall (%s); CPU checker local step %.1f s on 2 threads; "
           "%d windows" % (gpu_s, "; ".join(l for l in r.stdout.splitlines() if l.startswith("faldoi_flow")), cpu_s, st[1] + st[4]))
 
