@@ -252,3 +252,18 @@ def test_batch_host_failures_reach_every_rank(bins, tmp_path):
     assert r.returncode == 3 and "cannot be mixed" in r.stderr
     r = subprocess.run([bins["faldoi_batch_stub"]], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "usage" in r.stderr
+
+
+def test_batch_host_without_a_gpu_ends_every_rank(bins, tmp_path):
+    """The RCCL build of faldoi_batch on a machine without a GPU (this container): rank 0 cannot get a communicator id, says so and
+    exits 3; the ranks it had already started find their pipe closed and leave with 3 as well -- nobody is left waiting."""
+    import ctypes as C
+    n = C.c_int(0)
+    if F.capi.lib().faldoi_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present: the GPU suite runs this program for real")
+    rng = np.random.default_rng(5)
+    jobs, _ = _batch_inputs(tmp_path, 2, False, rng)
+    for gpus in ("1", "3"):
+        r = subprocess.run([bins["faldoi_batch"], str(jobs), "-gpus", gpus], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 3, (gpus, r.returncode, r.stderr[-500:])
+        assert "faldoi_batch:" in r.stderr
