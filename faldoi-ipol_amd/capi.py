@@ -18,7 +18,7 @@ MAX_CHUNK = 16
 # every symbol include/faldoi_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "faldoi_abi_version", "faldoi_device_count", "faldoi_ctx_create", "faldoi_ctx_destroy",
-    "faldoi_ctx_synchronize", "faldoi_ctx_persist_stats", "faldoi_ctx_persist_retry", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
+    "faldoi_ctx_synchronize", "faldoi_ctx_persist_stats", "faldoi_ctx_persist_retry", "faldoi_ctx_exact_redos", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
     "faldoi_tvl1_batch_create", "faldoi_tvl1_batch_destroy", "faldoi_tvl1_batch_upload",
     "faldoi_tvl1_batch_reset", "faldoi_tvl1_batch_solve", "faldoi_tvl1_batch_download",
     "faldoi_tvl1_batch_last_timing", "faldoi_tvl1_batch_last_schedule", "faldoi_tvl1_batch_last_persistent", "faldoi_tvl1_schedule_query", "faldoi_centered_gradient", "faldoi_forward_gradient",
@@ -103,6 +103,7 @@ def lib():
     L.faldoi_ctx_synchronize.argtypes = [vp]
     L.faldoi_ctx_persist_stats.argtypes = [vp] + [C.POINTER(C.c_long)] * 4
     L.faldoi_ctx_persist_retry.argtypes = [vp]
+    L.faldoi_ctx_exact_redos.argtypes = [vp, C.POINTER(C.c_long)]
     L.faldoi_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
     L.faldoi_tvl1_default_params.restype = None
     L.faldoi_tvl1_global.argtypes = [vp, _F, _F, _F, vp, C.c_int, C.c_int, C.POINTER(Tvl1Params),
@@ -219,6 +220,12 @@ class Context:
 
     def persist_retry(self):
         _check(lib().faldoi_ctx_persist_retry(self._h))
+
+    def exact_redos(self):
+        """Solves repeated with the general quotients (a divisor was an even integer >= 6: images that were not normalised)."""
+        n = C.c_long(0)
+        _check(lib().faldoi_ctx_exact_redos(self._h, C.byref(n)))
+        return n.value
 
     # ---- primitives (host arrays in/out) ----
     def centered_gradient(self, img):
@@ -402,8 +409,9 @@ class Context:
     def selftest_division(self, count=1 << 28, seed=12345):
         bad = C.c_ulonglong(0)
         _check(lib().faldoi_selftest_division(self._h, int(seed), int(count), C.byref(bad)))
+        self.selftest_report = lib().faldoi_last_error().decode()      # breakdown, incl. what the one-product form refused
         if bad.value:
-            print(lib().faldoi_last_error().decode())
+            print(self.selftest_report)
         return bad.value
 
     # ---- one-call solver (mirror of tvl2OF) ----

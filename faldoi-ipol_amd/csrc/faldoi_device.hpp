@@ -67,6 +67,53 @@ __device__ __forceinline__ float div_by(float a, float d, double rd)
     return (float)__builtin_fma(nrem, -rd, q0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same quotient as ONE fp64 product, for divisors that are constant over many quotients (theta: a solve; |grad I|^2: a warp):
+//
+//   rd  = 1/d to within 2^-52 relative (recip_f64_full: two Newton steps; on the host 1.0 / (double)d)
+//   result = (float)((double)a * rd)                 cvt + mul + cvt instead of cvt + mul + 2 fma + cvt
+//
+// q0 = a * rd is within 2^-52 + 2^-53 of a/d (relative).  (float)q0 == RN(a/d) unless a boundary of the fp32 rounding (the midpoint of
+// two neighbouring floats, 2^-150, or the overflow threshold) lies between q0 and a/d.  With d = D * 2^f, a = A * 2^g (D, A < 2^24):
+//  * result in the normal range or overflowing: a boundary m has 25 significant bits, so a - d*m is a non-zero multiple of
+//    2^min(g, f + e - 24) (D*m keeps an odd part of >= 25 bits: it is never a float) and |a/d - m| >= 2^-49 |a/d| -- eight times the
+//    error of q0.  A quotient that is exactly a float is rounded to itself.
+//  * result subnormal (or rounding to zero): the boundaries are the odd multiples of 2^-150.  a - d*m is a multiple of
+//    2^min(g, f - 150); if it is not zero, |a/d - m| >= 2^-48 |a/d| (f - 150 <= g: at least 2^-150 / D against |a/d| < 2^-126;
+//    otherwise at least 2^g = |a| / A).  It IS zero -- an exact tie, which RN breaks to even and a perturbed q0 may not -- only if
+//    d * (2k+1) * 2^-150 is a float of that magnitude: d = (odd) * 2^f with f >= 1, i.e. d is an even integer; and when its odd
+//    part is 1 (a power of two) rd and q0 are exact and the conversion breaks the tie itself.
+// Hence div_once_ok(d): everything except the even integers >= 6.  Callers test it once per divisor (a wave-uniform flag) and use div_by
+// for the others.  Signed zeros, NaN and subnormal numerators behave as in div_by; an infinite numerator gives the IEEE infinity.
+// Checked against the hardware IEEE divide by faldoi_selftest_division: random bit patterns and tie makers for random divisors, and
+// EVERY numerator for theta = 0.3f.  (Measured: 11.85 -> 11.5 ms per 300 x 10 solve.  For the duals -- a new divisor per pixel and
+// iteration -- the two extra Newton steps and the per-pixel test cost more than the two fma per quotient they save: not used there.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double recip_f64_full(float d)
+{
+    const double dd = (double)d;
+    const double r0 = __builtin_amdgcn_rcp(dd);
+    const double e0 = __builtin_fma(-dd, r0, 1.0);
+    const double r1 = __builtin_fma(e0, r0, r0);               // >= 2^-40
+    const double e1 = __builtin_fma(-dd, r1, 1.0);
+    return __builtin_fma(e1, r1, r1);                          // (1/d)(1 - e1^2) rounded once: <= 2^-53 + 2^-79
+}
+__device__ __forceinline__ bool div_once_ok(float d)           // false: d is an even integer >= 6 (every float >= 2^24 is one)
+{
+    return !(d >= 6.0f) || __builtin_amdgcn_fractf(0.5f * d) != 0.0f;
+}
+__device__ __forceinline__ float div_once(float a, double rd)
+{
+    return (float)((double)a * rd);
+}
+// a / d by whichever form the caller has established for its divisors.  ONCE is a compile-time choice: the callers branch once per
+// phase on a wave-uniform flag and instantiate both bodies (a branch per quotient was measured: it costs what the shorter form saves).
+template <bool ONCE>
+__device__ __forceinline__ float div_const(float a, float d, double rd)
+{
+    return ONCE ? div_once(a, rd) : div_by(a, d, rd);
+}
+
 // (Measured and not adopted: x / theta as fma(x, zh, x*zl) with zh + zl ~ 1/theta -- Brisebarre, Muller, Raina 2004 -- proved per
 // theta by an exhaustive comparison over all 2^32 numerators; theta = 0.3 passes for |x| >= 2^-100.  Unguarded it saves 2.3 % of a
 // solve; the wave-uniform guard for tiny non-zero numerators costs the same 2.3 %.)
@@ -285,8 +332,10 @@ __device__ __forceinline__ float grad_sq(float I1wx, float I1wy)
 // :690-718 thresholding step: v = u + TH(rho, grad).
 // rgrad = recip_f64(grad), constant over a launch; the reference's `fi = -rho / grad` is obtained
 // as the exact quotient div_by(-rho, grad, rgrad) (grad >= 1e-8 > 0 wherever fi is selected; for
-// smaller grad the value is computed but discarded).  Branch-free: one selected factor f with
+// smaller grad the value is computed but discarded).  ONCE: the caller guarantees rgrad = recip_f64_full(grad)
+// and div_once_ok(grad) for every lane -- the one-product form.  Branch-free: one selected factor f with
 // d = f * I1w{x,y}; the three explicit factors are the reference's own operands (l_t, -l_t, fi).
+template <bool ONCE = false>
 __device__ __forceinline__ void threshold_step(float rho_c, float I1wx, float I1wy, float grad, double rgrad,
                                                float u1, float u2, float l_t, float &v1, float &v2)
 {
@@ -294,7 +343,7 @@ __device__ __forceinline__ void threshold_step(float rho_c, float I1wx, float I1
     const float lg = l_t * grad;
     const bool below = rho < -lg;                 // (-l_t)*grad == -(l_t*grad) exactly
     const bool above = rho > lg;
-    const float fi = (kWhatIf & 4) ? -rho * (float)rgrad : div_by(-rho, grad, rgrad);
+    const float fi = (kWhatIf & 4) ? -rho * (float)rgrad : div_const<ONCE>(-rho, grad, rgrad);
     const float f = below ? l_t : (above ? -l_t : fi);
     float d1 = f * I1wx;
     float d2 = f * I1wy;
@@ -339,14 +388,15 @@ __device__ __forceinline__ void dual_step(float &xi11, float &xi12, float &xi21,
 
 // :307-342 ofTVl2_getP for one pixel, followed by the over-relaxation of :780-783.
 // Returns |du|^2 (u_N).
-// rtheta = fp64 reciprocal of theta (host: 1.0 / (double)theta), see div_by.
+// rtheta = fp64 reciprocal of theta (host: 1.0 / (double)theta), see div_by; ONCE: div_once_ok(theta) holds, the one-product form.
+template <bool ONCE = false>
 __device__ __forceinline__ float primal_step(float &u1, float &u2, float &ub1, float &ub2,
                                              float v1, float v2, float div1, float div2,
                                              float theta, double rtheta, float tau)
 {
     const float u1k = u1, u2k = u2;
-    const float q1 = (kWhatIf & 8) ? (u1k - v1) * (float)rtheta : div_by(u1k - v1, theta, rtheta);
-    const float q2 = (kWhatIf & 8) ? (u2k - v2) * (float)rtheta : div_by(u2k - v2, theta, rtheta);
+    const float q1 = (kWhatIf & 8) ? (u1k - v1) * (float)rtheta : div_const<ONCE>(u1k - v1, theta, rtheta);
+    const float q2 = (kWhatIf & 8) ? (u2k - v2) * (float)rtheta : div_const<ONCE>(u2k - v2, theta, rtheta);
     const float n1 = u1k - tau * (-div1 + q1);
     const float n2 = u2k - tau * (-div2 + q2);
     const float e = (n1 - u1k) * (n1 - u1k) + (n2 - u2k) * (n2 - u2k);

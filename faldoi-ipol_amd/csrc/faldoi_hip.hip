@@ -122,6 +122,7 @@ struct faldoi_ctx {
     int n_cu = 256;
     // What this context has seen of the persistent TV-L1 kernel (tvl1_persist_kernel.hpp), faldoi_ctx_persist_stats:
     long persist_launches = 0;        // solves that ran as one persistent launch
+    long exact_redos = 0;             // solves repeated with the general quotients (faldoi_device.hpp: div_once_ok)
     long persist_fallbacks = 0;       // launches that gave up waiting (workgroups not all resident) and were redone per launch
     long persist_busy = 0;            // solves kept off the persistent path because the device had other work of this process
     long persist_backed_off = 0;      // solves kept off it while backing off after a give-up
@@ -196,6 +197,7 @@ struct faldoi_tvl1_batch {
     int *d_done = nullptr;
     std::vector<int> final_cur;       // which state buffer holds each pair's result
     std::vector<char> uploaded;
+    bool exact_quot = false;          // a solve of these images met a divisor the one-product quotient must not be used with
     bool solved = false;
     double last_ms = 0.0;
     double last_chunk_ms = 0.0;       // sum of per-launch event times of the fused kernel (0 = not measured)
@@ -314,6 +316,13 @@ extern "C" int faldoi_ctx_persist_retry(faldoi_ctx *c)
     return FALDOI_OK;
 }
 
+extern "C" int faldoi_ctx_exact_redos(faldoi_ctx *c, long *redos)
+{
+    if (!c || !redos) return fail(FALDOI_ERR_INVALID, "NULL argument");
+    *redos = c->exact_redos;
+    return FALDOI_OK;
+}
+
 static float *plane_ptr(faldoi_tvl1_batch *b, int pair, int plane);
 static int prim_check(faldoi_ctx *ctx, int nx, int ny);
 
@@ -355,12 +364,12 @@ static void pick_schedule(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *
     *chunk = k;
 }
 
-template <int R, int NW>
+template <int R, int NW, bool ONCE>
 static hipError_t launch_chunk_t(dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int ntx, int nty,
                                  int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st, int cur,
                                  int first, int iters, int slot, unsigned long long *stamps)
 {
-    hipLaunchKernelGGL((tvl1_chunk_kernel<R, NW>), grid, dim3(64 * NW), 0, s, base, pe, nx, ny, ntx, nty, npairs, halo,
+    hipLaunchKernelGGL((tvl1_chunk_kernel<R, NW, ONCE>), grid, dim3(64 * NW), 0, s, base, pe, nx, ny, ntx, nty, npairs, halo,
                        prm, ctl, err, st, cur, first, iters, slot, stamps);
     return hipGetLastError();
 }
@@ -369,10 +378,12 @@ static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base
                                int nty, int npairs, int halo, TvConst prm, const PairCtl *ctl, float *err, int st,
                                int cur, int first, int iters, int slot, unsigned long long *stamps = nullptr)
 {
-#define FALDOI_CASE(r, w)                                                                                             \
-    if (tc.R == r && tc.NW == w)                                                                                      \
-        return launch_chunk_t<r, w>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, first, \
-                                    iters, slot, stamps);
+#define FALDOI_CASE(r, w)                                                                                                    \
+    if (tc.R == r && tc.NW == w)                                                                                             \
+        return prm.once ? launch_chunk_t<r, w, true>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur,  \
+                                                     first, iters, slot, stamps)                                             \
+                        : launch_chunk_t<r, w, false>(grid, s, base, pe, nx, ny, ntx, nty, npairs, halo, prm, ctl, err, st, cur, \
+                                                      first, iters, slot, stamps);
     FALDOI_CASE(4, 16)
     FALDOI_CASE(3, 12)
     FALDOI_CASE(4, 12)
@@ -386,7 +397,7 @@ static hipError_t launch_chunk(TileCfg tc, dim3 grid, hipStream_t s, float *base
 }
 
 static void launch_warp(int variant, dim3 grid, hipStream_t s, float *base, size_t pe, int nx, int ny, int npairs,
-                        const PairCtl *ctl, int st, int cur)
+                        PairCtl *ctl, int st, int cur)
 {
     // FALDOI_WARP_LDS=bytes (tuning aid): unused dynamic LDS per workgroup, which caps how many workgroups a CU keeps resident
     // (the kernel's waves all gather, then all compute; fewer resident waves stagger the two phases)
@@ -458,7 +469,8 @@ static hipError_t launch_persist(const PersistCfg &pc, dim3 grid, hipStream_t s,
 {
 #define FALDOI_CASE(r, w)                                                                          \
     if (pc.R == r && pc.NW == w) {                                                                 \
-        hipLaunchKernelGGL((tvl1_persist_kernel<r, w>), grid, dim3(64 * w), 0, s, a);              \
+        if (a.prm.once) hipLaunchKernelGGL((tvl1_persist_kernel<r, w, true>), grid, dim3(64 * w), 0, s, a);   \
+        else hipLaunchKernelGGL((tvl1_persist_kernel<r, w, false>), grid, dim3(64 * w), 0, s, a);  \
         return hipGetLastError();                                                                  \
     }
     FALDOI_CASE(3, 16)
@@ -475,10 +487,12 @@ static hipError_t launch_persist_dyn(const PersistCfg &pc, dim3 grid, hipStream_
     if (pc.R != 3 || pc.NW != 16) return hipErrorInvalidValue;
     const size_t lds = 8ull * 3 * 64 * 16 * sizeof(float);             // the snapshot: 96 KB beside 21 KB static (160 KB per CU)
     // per device, so not cached in a static: a process may hold contexts on several devices
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&tvl1_persist_dyn_kernel<3, 16>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void *fn = a.prm.once ? reinterpret_cast<const void *>(&tvl1_persist_dyn_kernel<3, 16, true>)
+                                : reinterpret_cast<const void *>(&tvl1_persist_dyn_kernel<3, 16, false>);
+    const hipError_t attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((tvl1_persist_dyn_kernel<3, 16>), grid, dim3(64 * 16), lds, s, a);
+    if (a.prm.once) hipLaunchKernelGGL((tvl1_persist_dyn_kernel<3, 16, true>), grid, dim3(64 * 16), lds, s, a);
+    else hipLaunchKernelGGL((tvl1_persist_dyn_kernel<3, 16, false>), grid, dim3(64 * 16), lds, s, a);
     return hipGetLastError();
 }
 
@@ -561,6 +575,7 @@ static int faldoi_tvl1_batch_upload_impl(faldoi_tvl1_batch *b, int pair, const f
     }
     HIP_TRY(hipStreamSynchronize(s));
     b->uploaded[pair] = 1;
+    b->exact_quot = false;
     b->solved = false;
     return FALDOI_OK;
 }
@@ -637,6 +652,12 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
 
     TvConst k;
     k.rtheta = 1.0 / (double)prm->theta;
+    // The quotients by theta and |grad I|^2 as one fp64 product each (faldoi_device.hpp: div_once) -- unless a divisor is an even
+    // integer >= 6 (div_once_ok).  theta is tested here; the kernels that compute warp constants report such a |grad I|^2 (images
+    // that were never normalised) in PairCtl::unsafe, and the solve is then repeated below in the general form, which this batch
+    // keeps until its next upload.  FALDOI_EXACT_QUOTIENTS=1 selects the general form from the start (tests).
+    static const bool env_exact = [] { const char *v = getenv("FALDOI_EXACT_QUOTIENTS"); return v && atoi(v) > 0; }();
+    k.once = !(prm->theta >= 6.0f && std::fmod(0.5f * prm->theta, 1.0f) == 0.0f) && !b->exact_quot && !env_exact;
     k.l_t = prm->lambda * prm->theta;          // src/global_faldoi.cpp:577
     k.theta = prm->theta;
     k.tau = prm->tau;
@@ -744,6 +765,7 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         if (const char *v = getenv("FALDOI_PERSIST_SPINS")) { const long q = atol(v); if (q >= 0 && q < (1L << 31)) a.spin_limit = (unsigned)q; }
         a.stamps = p_stamps;
         a.stamp_warp = warps / 2;
+        a.unsafe = &b->ctl[0].unsafe;
         a.err_board = b->xflags + flag_words;
         a.iters_out = b->d_iters;
         a.werr_out = b->d_err;
@@ -832,15 +854,17 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     HIP_TRY(hipEventRecord(c->ev1, s));
     // the per-warp iteration counts and errors follow the solve down the same stream into pinned memory: one wait for everything
     const size_t nstat = (size_t)warps * b->npairs;
-    if (c->h_stats_cap < 2 * nstat) {
+    if (c->h_stats_cap < 2 * nstat + b->npairs) {
         if (c->h_stats) (void)hipHostFree(c->h_stats);
         c->h_stats = nullptr;
         c->h_stats_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&c->h_stats, sizeof(int) * 2 * nstat, hipHostMallocDefault));
-        c->h_stats_cap = 2 * nstat;
+        HIP_TRY(hipHostMalloc((void **)&c->h_stats, sizeof(int) * (2 * nstat + b->npairs), hipHostMallocDefault));
+        c->h_stats_cap = 2 * nstat + b->npairs;
     }
     HIP_TRY(hipMemcpyAsync(c->h_stats, b->d_iters, sizeof(int) * nstat, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(c->h_stats + nstat, b->d_err, sizeof(float) * nstat, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpy2DAsync(c->h_stats + 2 * nstat, sizeof(int), &b->ctl[0].unsafe, sizeof(PairCtl), sizeof(int), b->npairs,
+                             hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -868,6 +892,15 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     if (persist) {
         ++c->persist_launches;
         c->persist_backoff_len = 0;
+    }
+    if (k.once) {
+        bool unsafe = false;
+        for (int i = 0; i < b->npairs; ++i) unsafe = unsafe || c->h_stats[2 * nstat + i] != 0;
+        if (unsafe) {                             // a |grad I|^2 that is an even integer >= 6: the general quotient, from the start
+            b->exact_quot = true;
+            ++c->exact_redos;
+            return faldoi_tvl1_batch_solve_impl(b, prm, stats, scope);
+        }
     }
     if (p_stamps_out) { const int rc = probe_report_persistent(p_stamps_out, ntiles, ntx, nty, warps); if (rc) return rc; }   // tvl1_probe_host.inc
     if (d_stamps) { const int rc = probe_report_chunk(d_stamps, total_tiles, ntx, nty); if (rc) return rc; }
@@ -1230,6 +1263,7 @@ static int faldoi_tvl1_batch_upload_images_impl(faldoi_tvl1_batch *b, int pair, 
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(FALDOI_ERR_HIP, "upload failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     b->uploaded[pair] = 1;
+    b->exact_quot = false;
     b->solved = false;
     return FALDOI_OK;
 }
@@ -1675,7 +1709,7 @@ static int faldoi_selftest_division_impl(faldoi_ctx *ctx, unsigned seed, unsigne
     if (!ctx || !mismatches) return fail(FALDOI_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
     unsigned long long *d = nullptr;
-    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float *dump = nullptr;
     const int dump_cap = getenv("FALDOI_SELFTEST_DUMP") ? 64 : 0;
     if (dump_cap) HIP_TRY(hipMalloc((void **)&dump, sizeof(float) * 4 * dump_cap));
@@ -1701,9 +1735,11 @@ static int faldoi_selftest_division_impl(faldoi_ctx *ctx, unsigned seed, unsigne
     (void)hipFree(d);
     if (e != hipSuccess) return fail(FALDOI_ERR_HIP, "selftest failed: %s", hipGetErrorString(e));
     *mismatches = h[0];
-    if (h[0])   // breakdown for the error text: dual-site, subnormal-result, huge-divisor cases
-        fail(FALDOI_OK, "division selftest: %llu mismatches (dual site %llu, subnormal result %llu, divisor>1e30 %llu)",
-             h[0], h[1], h[2], h[3]);
+    // breakdown for the text of faldoi_last_error: dual-site, subnormal-result, huge-divisor cases; the one-product form, the
+    // divisors it refuses (div_once_ok) and how many of their quotients it would have got wrong
+    fail(FALDOI_OK, "division selftest: %llu mismatches (dual site %llu, subnormal result %llu, divisor>1e30 %llu, one-product form "
+         "%llu); one-product form refused %llu quotients, %llu of them would differ",
+         h[0], h[1], h[2], h[3], h[5], h[6], h[7]);
     return FALDOI_OK;
 }
 

@@ -16,6 +16,7 @@
 // across wave boundaries where one row per wave is exchanged through LDS.
 #pragma once
 #include "faldoi_device.hpp"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -36,6 +37,7 @@ enum Plane {
 
 struct TvConst {
     double rtheta;                 // 1 / (double)theta, for the exact fp64-assisted quotient
+    int once;                      // host side only: launch the instantiations with the one-product quotients (ONCE)
     float l_t, theta, tau, tol2;
     int max_inner, tol_stop, warps, chunk;
 };
@@ -50,7 +52,7 @@ struct PairCtl {
     int iters;       // inner iterations the next chunk launch must run (0 = nothing to do)
     int redo;        // next chunk is the exact-length re-run that ends the warp
     int done;        // all warps finished
-    int pad;
+    int unsafe;      // raised by the kernels that compute warp constants: a |grad I|^2 that does not admit the one-product quotient
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -123,7 +125,8 @@ __global__ void bicubic_warp_kernel(const float *__restrict__ in, const float *_
 // hardware IEEE fp32 divide.  Sample i draws a numerator from a counter-based hash over ALL finite
 // bit patterns (every exponent incl. subnormals, both signs; every 16th sample is a special value)
 // and divides it (a) by max(1,|x|) for a hashed x, the dual step's divisor, and (b) by a hashed
-// theta in (2^-20, 4), the primal step's divisor.  Counts bitwise mismatches.
+// theta in (2^-20, 4), the primal step's divisor.  Counts bitwise mismatches.  mismatch[0] total, [1] dual site, [2] subnormal
+// results, [3] huge divisors, [4] dump cursor, [5] one-product form, [6] divisors that form refuses, [7] ... of which it would get wrong.
 __device__ __forceinline__ unsigned mix32(unsigned x)
 {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -175,6 +178,49 @@ __global__ void selftest_division_kernel(unsigned seed, unsigned long long count
         bad += m2;
         bad_sub += m2 && (fabsf(t_ref) < 1.17549435e-38f);
     }
+    // (c) the one-product form (div_once): theta as above; a divisor as |grad I|^2 can be -- any magnitude in [2^-30, 2^30), every
+    // fourth a small integer (the even ones >= 6 must be refused by div_once_ok, and are counted); numerators: the hashed one and a
+    // tie maker d * (2k+1) * 2^-150 rounded to a float (an exact tie whenever that product is a float).  recip_f64_full must be within
+    // one fp64 ulp of the correctly rounded reciprocal.
+    unsigned long long bad_once = 0, refused = 0, forced = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned h0 = mix32((unsigned)i ^ seed ^ 0x5bd1e995u), h1 = mix32(h0 + 0x9e3779b9u + (unsigned)(i >> 32));
+        const unsigned h2 = mix32(h1 ^ 0xc2b2ae35u);
+        unsigned ab = h0;
+        if ((i & 15) == 0) ab = (h0 & 0x80ffffffu);                    // subnormals and the smallest normals
+        if ((ab & 0x7f800000u) == 0x7f800000u) ab &= 0xbfffffffu;
+        float d = __uint_as_float(((97u + (h2 >> 8) % 60u) << 23) | (h1 & 0x007fffffu));
+        if ((i & 3) == 2) d = (float)(1u + (h1 % 4096u)) * (float)(1u << ((h2 >> 4) & 3u));
+        if ((i & 63) == 5) d = 0.3f;
+        const double rd = recip_f64_full(d);
+        const double rn = 1.0 / (double)d;
+        long long ulps = (long long)__double_as_longlong(rd) - (long long)__double_as_longlong(rn);
+        bad_once += (ulps > 1 || ulps < -1);
+        const float tie = (float)((double)d * (double)(2u * (h0 % 1000u) + 1u) * 0x1p-150);
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const float a = w ? (((h2 >> 1) & 1u) ? -tie : tie) : __uint_as_float(ab);
+            const bool differs = __float_as_uint(a / d) != __float_as_uint(div_once(a, rd));
+            if (div_once_ok(d)) bad_once += differs;
+            else { refused += 1; forced += differs; }
+        }
+    }
+    // ... and every numerator for the default theta (NaN numerators: any NaN is accepted)
+    {
+        const float theta = 0.3f;
+        const double rtheta = 1.0 / (double)theta;
+        for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < (1ull << 32);
+             i += (unsigned long long)gridDim.x * blockDim.x) {
+            const float a = __uint_as_float((unsigned)i);
+            const float q_ref = a / theta, q_new = div_once(a, rtheta);
+            bad_once += (__float_as_uint(q_ref) != __float_as_uint(q_new)) && !(q_ref != q_ref && q_new != q_new);
+        }
+    }
+    bad += bad_once;
+    if (refused) atomicAdd(mismatch + 6, refused);
+    if (forced) atomicAdd(mismatch + 7, forced);
+    if (bad_once) atomicAdd(mismatch + 5, bad_once);
     // exhaustive: sqrt(g*g) == |g| for every float the fast path of sqrt_of_square accepts
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < (1ull << 32);
          i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -216,7 +262,7 @@ __global__ void reset_state_kernel(float *__restrict__ base, size_t plane_elems,
     }
     if (blockIdx.x == 0 && threadIdx.x < npairs) {
         PairCtl c;
-        c.warp = 0; c.n = 0; c.cur = 0; c.first = 1; c.iters = first_iters; c.redo = 0; c.done = 0; c.pad = 0;
+        c.warp = 0; c.n = 0; c.cur = 0; c.first = 1; c.iters = first_iters; c.redo = 0; c.done = 0; c.unsafe = 0;
         ctl[threadIdx.x] = c;
     }
 }
@@ -229,7 +275,7 @@ __global__ void reset_state_kernel(float *__restrict__ base, size_t plane_elems,
 // ---------------------------------------------------------------------------------------------
 template <int WPS>
 __global__ __launch_bounds__(256, WPS) void tvl1_warp_kernel(float *__restrict__ base, size_t plane_elems, int nx, int ny,
-                                                          int npairs, const PairCtl *__restrict__ ctl, int static_mode,
+                                                          int npairs, PairCtl *__restrict__ ctl, int static_mode,
                                                           int s_cur)
 {
     const int npix = nx * ny;
@@ -267,6 +313,9 @@ __global__ __launch_bounds__(256, WPS) void tvl1_warp_kernel(float *__restrict__
     slab[(size_t)P_RC * plane_elems + p] = rho_const(w0, wx, wy, u1, u2, i0v);
     slab[(size_t)P_IWX * plane_elems + p] = wx;
     slab[(size_t)P_IWY * plane_elems + p] = wy;
+    // a divisor the one-product quotient must not be used with (an even integer >= 6, faldoi_device.hpp): tell the host, which
+    // repeats the solve with the general form if it ran the other one
+    if (!div_once_ok(grad_sq(wx, wy))) ctl[pair].unsafe = 1;
     // ubar = u (:659-660) is not materialised: the first chunk of a warp takes ubar from u.
 }
 
@@ -293,9 +342,20 @@ template <int R>
 struct TileState {
     float u1[R], u2[R], ub1[R], ub2[R], x11[R], x12[R], x21[R], x22[R];   // flow, over-relaxed flow, duals
     float rc[R], ix[R], iy[R], gr[R];                                      // warp constants, |grad I|^2
-    double rgr[R];                                                         // fp64 reciprocal of gr, constant over a warp
+    double rgr[R];                                                         // fp64 reciprocal of gr (recip_f64 / _full), constant over a warp
     bool own[R];                                                           // pixel stored by this tile
 };
+
+// Wave-uniform: every |grad I|^2 held by this wave admits the one-product quotient (faldoi_device.hpp: div_once_ok).  Every lane
+// of the wave must be here.
+template <int R>
+__device__ __forceinline__ bool tile_div_once(const TileState<R> &s)
+{
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) ok = ok && div_once_ok(s.gr[r]);
+    return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+}
 
 // `iters` primal-dual iterations (src/global_faldoi.cpp:684-783) on the tile held in `s`; shared by the per-launch kernel
 // below and by the persistent kernel (tvl1_persist_kernel.hpp).  halo_y = rows of halo above and below the owned rows; the
@@ -307,7 +367,11 @@ struct TvNoHook {
 // `after_duals(it)`: called by every thread of a computing wave once the duals of iteration `it` are final (before the barrier that
 // precedes the primal step) -- the persistent kernel publishes the ring's duals from there in the last iteration of a chunk.
 // `after_primal(it)`: the same once flow and ubar of iteration `it` are final.
-template <int R, int NW, int BORDER, typename Hook = TvNoHook, typename Hook2 = TvNoHook>
+// ONCE: the quotients by |grad I|^2 and theta in the one-product form (faldoi_device.hpp: div_once).  A property of the whole solve,
+// chosen by the host; the kernels that compute warp constants report divisors that do not admit it (TvConst / PersistArgs: unsafe) and
+// the host then repeats the solve with ONCE = false.  (A wave-uniform choice inside the kernel -- per quotient, per phase, or two copies
+// of this loop -- was built and measured: the branch and the second copy's registers cost what the shorter form saves.)
+template <int R, int NW, int BORDER, bool ONCE, typename Hook = TvNoHook, typename Hook2 = TvNoHook>
 __device__ __forceinline__ void tvl1_iterate(TileState<R> &s, int iters, int halo_y, int gx, int gy0, int nx, int ny,
                                              int lane, int wv, bool wave_live, const TvConst &prm,
                                              float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
@@ -377,9 +441,9 @@ __device__ __forceinline__ void tvl1_iterate(TileState<R> &s, int iters, int hal
                     div2 = (s.x21[r] - l21) + (s.x22[r] - t22);
                 }
                 float v1, v2;
-                threshold_step(s.rc[r], s.ix[r], s.iy[r], s.gr[r], s.rgr[r], s.u1[r], s.u2[r], prm.l_t, v1, v2);
-                const float e = primal_step(s.u1[r], s.u2[r], s.ub1[r], s.ub2[r], v1, v2, div1, div2, prm.theta,
-                                            prm.rtheta, prm.tau);
+                threshold_step<ONCE>(s.rc[r], s.ix[r], s.iy[r], s.gr[r], s.rgr[r], s.u1[r], s.u2[r], prm.l_t, v1, v2);
+                const float e = primal_step<ONCE>(s.u1[r], s.u2[r], s.ub1[r], s.ub2[r], v1, v2, div1, div2, prm.theta,
+                                                  prm.rtheta, prm.tau);
                 emax = (s.own[r] && e > emax) ? e : emax;
             }
             s_ub1[wv][lane] = s.ub1[0];
@@ -408,7 +472,7 @@ __device__ __forceinline__ void tvl1_store_errors(unsigned (*s_err)[kTileW], int
     }
 }
 
-template <int R, int NW, int BORDER>
+template <int R, int NW, int BORDER, bool ONCE>
 __device__ __forceinline__ void tvl1_chunk_body(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int npairs, int ntiles, int t,
     int pair, int txi, int tyi, int halo, const TvConst &prm, float *__restrict__ err_out,
@@ -453,7 +517,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
         s.ix[r] = in[r] ? iwxp[p] : 0.0f;
         s.iy[r] = in[r] ? iwyp[p] : 0.0f;
         s.gr[r] = grad_sq(s.ix[r], s.iy[r]);                    // src/global_faldoi.cpp:648-652
-        s.rgr[r] = recip_f64(s.gr[r]);
+        s.rgr[r] = ONCE ? recip_f64_full(s.gr[r]) : recip_f64(s.gr[r]);
     }
     const bool ends_warp = (first & 2) != 0;                    // the launch surely ends its warp: ubar is dead afterwards
     first &= 1;
@@ -481,7 +545,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
 
     // (storing the four dual planes from inside the last iteration -- they are final after its dual step -- was measured here too:
     // no gain, 13.85 against 13.82 ms per solve; plain stores at a kernel's end stall nobody, unlike the persistent kernel's drain)
-    tvl1_iterate<R, NW, BORDER>(s, iters, halo, gx, gy0, nx, ny, lane, wv, wave_live, prm, s_ub1, s_ub2, s_x12, s_x22, s_err);
+    tvl1_iterate<R, NW, BORDER, ONCE>(s, iters, halo, gx, gy0, nx, ny, lane, wv, wave_live, prm, s_ub1, s_ub2, s_x12, s_x22, s_err);
 
     if (stamps && threadIdx.x == 0) stamps[4 * t + 2] = __builtin_amdgcn_s_memrealtime();
     // ---- store the owned interior into the other state buffer ----
@@ -509,7 +573,7 @@ __device__ __forceinline__ void tvl1_chunk_body(
     tvl1_store_errors<NW>(s_err, iters, lane, wv, err_out + ((size_t)err_slot * ntiles * npairs + t) * kMaxChunk);
 }
 
-template <int R, int NW>
+template <int R, int NW, bool ONCE>
 __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     float *__restrict__ base, size_t plane_elems, int nx, int ny, int ntx, int nty, int npairs,
     int halo, TvConst prm, const PairCtl *__restrict__ ctl, float *__restrict__ err_out,
@@ -546,8 +610,8 @@ __global__ __launch_bounds__(64 * NW) void tvl1_chunk_kernel(
     const int X0 = txi * (kTileW - 2 * halo) - halo, Y0 = tyi * (TH - 2 * halo) - halo;
     const bool colb = X0 <= 0 || X0 + kTileW >= nx, rowb = Y0 <= 0 || Y0 + TH >= ny;
 #define FALDOI_BODY(B)                                                                                                  \
-    tvl1_chunk_body<R, NW, B>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out, cur,   \
-                              first, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err, stamps)
+    tvl1_chunk_body<R, NW, B, ONCE>(base, plane_elems, nx, ny, npairs, ntiles, t, pair, txi, tyi, halo, prm, err_out, \
+                                    cur, first, iters, err_slot, s_ub1, s_ub2, s_x12, s_x22, s_err, stamps)
     if (colb && rowb) FALDOI_BODY(3);
     else if (colb) FALDOI_BODY(1);
     else if (rowb) FALDOI_BODY(2);

@@ -24,7 +24,7 @@
 
 namespace faldoi {
 
-template <int R, int NW, int BORDER>
+template <int R, int NW, int BORDER, bool ONCE>
 __device__ __forceinline__ void tvl1_persist_dyn_body(const PersistArgs &a, int t, int txi, int tyi,
                                                       float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
                                                       float (*s_x22)[kTileW], unsigned (*s_err)[kTileW], int *s_ctl, float *s_dec,
@@ -68,7 +68,7 @@ __device__ __forceinline__ void tvl1_persist_dyn_body(const PersistArgs &a, int 
             __syncthreads();
             if (s_ctl[0]) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            px_fetch<R>(s, rsrc, par + g.src_off, g.plane_stride, g.halo, true);
+            px_fetch<R, ONCE>(s, rsrc, par + g.src_off, g.plane_stride, g.halo, true, a.unsafe);
         }
 
         int n = 0;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void tvl1_persist_dyn_body(const PersistArgs &a, int 
             auto early_flow = [&](int iter) {
                 if (kPersistEarlyDuals && g.ring && iter == it - 1) px_publish_flow<R>(s, rsrc, par_next + g.pub_off, g.plane_stride);
             };
-            tvl1_iterate<R, NW, BORDER>(s, it, a.hy, g.gx, g.gy0, nx, ny, lane, wv, g.wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
+            tvl1_iterate<R, NW, BORDER, ONCE>(s, it, a.hy, g.gx, g.gy0, nx, ny, lane, wv, g.wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
                                         s_err, early_duals, early_flow);
             __syncthreads();                                       // every iteration's per-lane maxima are in s_err
 
@@ -203,7 +203,7 @@ __device__ __forceinline__ void tvl1_persist_dyn_body(const PersistArgs &a, int 
                 }
                 s_ub1[wv][lane] = s.ub1[0];
                 s_ub2[wv][lane] = s.ub2[0];
-                tvl1_iterate<R, NW, BORDER>(s, stop_at + 1, a.hy, g.gx, g.gy0, nx, ny, lane, wv, g.wave_live, a.prm, s_ub1, s_ub2, s_x12,
+                tvl1_iterate<R, NW, BORDER, ONCE>(s, stop_at + 1, a.hy, g.gx, g.gy0, nx, ny, lane, wv, g.wave_live, a.prm, s_ub1, s_ub2, s_x12,
                                             s_x22, s_err);
                 __syncthreads();
                 for (int i = wv; i < kMaxChunk; i += NW) s_err[i][lane] = 0u;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void tvl1_persist_dyn_body(const PersistArgs &a, int 
             n += it;
             e_last = s_dec[it - 1];
             if (stop_at >= 0 || n >= a.prm.max_inner) break;
-            px_fetch<R>(s, rsrc, par + g.src_off, g.plane_stride, g.halo, false);
+            px_fetch<R, ONCE>(s, rsrc, par + g.src_off, g.plane_stride, g.halo, false, a.unsafe);
         }
         if (t == 0 && tid == 0) {
             a.iters_out[w] = n;
@@ -225,7 +225,7 @@ __device__ __forceinline__ void tvl1_persist_dyn_body(const PersistArgs &a, int 
     px_store_owned<R>(s, a, g);
 }
 
-template <int R, int NW>
+template <int R, int NW, bool ONCE>
 __global__ __launch_bounds__(64 * NW) void tvl1_persist_dyn_kernel(PersistArgs a)
 {
     constexpr int TH = R * NW;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void tvl1_persist_dyn_kernel(PersistArgs a
     const int tyi = t / a.ntx, txi = t - tyi * a.ntx;
     const int X0 = txi * (kTileW - 2 * a.hx) - a.hx, Y0 = tyi * (TH - 2 * a.hy) - a.hy;
     const bool colb = X0 <= 0 || X0 + kTileW >= a.nx, rowb = Y0 <= 0 || Y0 + TH >= a.ny;
-#define FALDOI_BODY(B) tvl1_persist_dyn_body<R, NW, B>(a, t, txi, tyi, s_ub1, s_ub2, s_x12, s_x22, s_err, s_ctl, s_dec, s_snap)
+#define FALDOI_BODY(B) tvl1_persist_dyn_body<R, NW, B, ONCE>(a, t, txi, tyi, s_ub1, s_ub2, s_x12, s_x22, s_err, s_ctl, s_dec, s_snap)
     if (colb && rowb) FALDOI_BODY(3);
     else if (colb) FALDOI_BODY(1);
     else if (rowb) FALDOI_BODY(2);

@@ -57,6 +57,7 @@ struct PersistArgs {
     unsigned spin_limit;
     unsigned long long *stamps;    // optional: [ntiles][kPersistStamps], taken during warp `stamp_warp`
     int stamp_warp;
+    int *unsafe;                   // raised when a |grad I|^2 does not admit the one-product quotient (PairCtl::unsafe of the pair)
     // tolerance stop on (tvl1_persist_dyn_kernel.hpp) only:
     unsigned *err_board;           // [2][ntiles][kMaxChunk] per-iteration tile maxima of the chunk just iterated (float bits)
     int *iters_out;                // [warps] iterations each warp ran, as the reference's `Warping: w,Iter: n` line
@@ -237,8 +238,9 @@ __device__ __forceinline__ void px_publish(const TileState<R> &s, RSRC rsrc, uns
 }
 
 // Fetch the halo from its owners' slabs (sc1 loads only); at a warp's start also ubar = u and the per-warp |grad I|^2.
-template <int R, typename RSRC>
-__device__ __forceinline__ void px_fetch(TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride, bool halo, bool first)
+template <int R, bool ONCE, typename RSRC>
+__device__ __forceinline__ void px_fetch(TileState<R> &s, RSRC rsrc, unsigned base, unsigned plane_stride, bool halo, bool first,
+                                         int *unsafe)
 {
     xvec4 q[kXPlanes];
 #pragma unroll
@@ -277,8 +279,10 @@ __device__ __forceinline__ void px_fetch(TileState<R> &s, RSRC rsrc, unsigned ba
             s.ub1[r] = s.u1[r];                                    // start of a warp: ubar = u (:659-660)
             s.ub2[r] = s.u2[r];
             s.gr[r] = grad_sq(s.ix[r], s.iy[r]);                   // :648-652
-            s.rgr[r] = recip_f64(s.gr[r]);
+            s.rgr[r] = ONCE ? recip_f64_full(s.gr[r]) : recip_f64(s.gr[r]);
         }
+        // every lane of the wave is here (`first` is uniform); a divisor that needs the general quotient is reported to the host
+        if (ONCE && !tile_div_once<R>(s) && (threadIdx.x & 63) == 0) *unsafe = 1;
     }
 }
 
@@ -327,7 +331,7 @@ __device__ __forceinline__ bool px_wait(const unsigned *flags, unsigned *abort_w
     }
 }
 
-template <int R, int NW, int BORDER>
+template <int R, int NW, int BORDER, bool ONCE>
 __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, int txi, int tyi,
                                                   float (*s_ub1)[kTileW], float (*s_ub2)[kTileW], float (*s_x12)[kTileW],
                                                   float (*s_x22)[kTileW], unsigned (*s_err)[kTileW], int *s_ctl)
@@ -394,7 +398,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the loads below the poll
             if (stamp) st[first ? 3 : 9] = __builtin_amdgcn_s_memrealtime();
 
-            px_fetch<R>(s, rsrc, par + src_off, plane_stride, halo, first);
+            px_fetch<R, ONCE>(s, rsrc, par + src_off, plane_stride, halo, first, a.unsafe);
             if (stamp) {
                 float sink = s.u1[0] + s.x22[R - 1] + s.iy[R - 1];
                 asm volatile("" : "+v"(sink));
@@ -416,7 +420,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
             auto early_flow = [&](int iter) {
                 if (kPersistEarlyFlow && !ends_warp && ring && iter == it - 1) px_publish_flow<R>(s, rsrc, par_next + pub_off, plane_stride);
             };
-            tvl1_iterate<R, NW, BORDER>(s, it, a.hy, gx, gy0, nx, ny, lane, wv, wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
+            tvl1_iterate<R, NW, BORDER, ONCE>(s, it, a.hy, gx, gy0, nx, ny, lane, wv, wave_live, a.prm, s_ub1, s_ub2, s_x12, s_x22,
                                         s_err, early_duals, early_flow);
             if (stamp) st[first ? 5 : 11] = __builtin_amdgcn_s_memrealtime();
 
@@ -432,7 +436,7 @@ __device__ __forceinline__ void tvl1_persist_body(const PersistArgs &a, int t, i
     px_store_owned<R>(s, a, g);
 }
 
-template <int R, int NW>
+template <int R, int NW, bool ONCE>
 __global__ __launch_bounds__(64 * NW) void tvl1_persist_kernel(PersistArgs a)
 {
     constexpr int TH = R * NW;
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(64 * NW) void tvl1_persist_kernel(PersistArgs a)
     const int tyi = t / a.ntx, txi = t - tyi * a.ntx;
     const int X0 = txi * (kTileW - 2 * a.hx) - a.hx, Y0 = tyi * (TH - 2 * a.hy) - a.hy;
     const bool colb = X0 <= 0 || X0 + kTileW >= a.nx, rowb = Y0 <= 0 || Y0 + TH >= a.ny;
-#define FALDOI_BODY(B) tvl1_persist_body<R, NW, B>(a, t, txi, tyi, s_ub1, s_ub2, s_x12, s_x22, s_err, s_ctl)
+#define FALDOI_BODY(B) tvl1_persist_body<R, NW, B, ONCE>(a, t, txi, tyi, s_ub1, s_ub2, s_x12, s_x22, s_err, s_ctl)
     if (colb && rowb) FALDOI_BODY(3);
     else if (colb) FALDOI_BODY(1);
     else if (rowb) FALDOI_BODY(2);

@@ -92,6 +92,10 @@ int faldoi_ctx_synchronize(faldoi_ctx *ctx);
  * Counters are per context, since its creation; any pointer may be NULL.  faldoi_ctx_persist_retry ends a back-off now. */
 int faldoi_ctx_persist_stats(faldoi_ctx *ctx, long *launches, long *fallbacks, long *busy, long *backed_off);
 int faldoi_ctx_persist_retry(faldoi_ctx *ctx);
+/* TV-L1 solves of this context that were repeated with the general form of the quotients by theta and |grad I|^2, because a divisor
+ * turned out to be an even integer >= 6 -- possible only for images that were not normalised to [0, 1] (faldoi_device.hpp: div_once;
+ * the result is the reference's either way, the repeat costs one solve and happens once per upload). */
+int faldoi_ctx_exact_redos(faldoi_ctx *ctx, long *redos);
 /* Thread-local text of the last failure (HIP error string, argument that was rejected). */
 const char *faldoi_last_error(void);
 void faldoi_tvl1_default_params(faldoi_tvl1_params *p);

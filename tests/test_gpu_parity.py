@@ -103,6 +103,12 @@ def test_fp64_assisted_quotient_equals_ieee_divide(ctx):
     # 2^30 hashed samples x 2 call sites, all exponents incl. subnormals and tie makers
     assert ctx.selftest_division(count=1 << 30, seed=1) == 0
     assert ctx.selftest_division(count=1 << 26, seed=0xdeadbeef) == 0
+    # the one-product form of the quotients by theta and |grad I|^2 (faldoi_device.hpp: div_once) is part of the same self-test: all
+    # numerators for theta = 0.3f, hashed ones and tie makers for hashed divisors.  Its refusal of even-integer divisors is not
+    # vacuous: the sample holds such divisors, and some of their tie quotients would indeed come out wrong.
+    import re
+    m = re.search(r"refused (\d+) quotients, (\d+) of them would differ", ctx.selftest_report)
+    assert m and int(m.group(1)) > 1000 and int(m.group(2)) > 0, ctx.selftest_report
 
 
 # ------------------------------------------------------------------ whole solver

@@ -438,3 +438,66 @@ def test_cpp_batch_host_over_rccl_single_rank(oracle, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     for i in range(len(crops)):
         assert bits_equal(F.flo.read_flo(str(tmp_path / ("q%d.flo" % i))), want[i]), i
+
+
+# ------------------------------------------------------------------ quotients by theta and |grad I|^2: the two forms
+@pytest.mark.parametrize("persist", ["1", "0"])
+@pytest.mark.parametrize("tol_stop", [0, 1])
+def test_even_integer_gradients_take_the_general_quotient(oracle, monkeypatch, persist, tol_stop):
+    """The TV-L1 kernels evaluate x / theta and -rho / |grad I|^2 as ONE fp64 product where that is proven to round like the IEEE
+    divide: for every divisor except the even integers >= 6 (faldoi_device.hpp: div_once, checked by the division self-test).
+    Images that were never normalised can produce such a |grad I|^2: a ramp 4x + 4y has I1x = I1y = 4 and |grad I|^2 = 32 at every
+    interior pixel of the first warp (zero flow: the bicubic warp returns the samples).  The kernel that computes the warp
+    constants -- the per-warp kernel, or the persistent kernel -- reports it, the library repeats the solve with the general
+    form (counted), keeps that form for the batch until its next upload, and the result is the CPU checker's bit for bit."""
+    monkeypatch.setenv("FALDOI_PERSIST", persist)
+    w, h = 160, 96
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    i0 = (4.0 * xx + 4.0 * yy).astype(np.float32)
+    i1 = (4.0 * (xx - 1.0) + 4.0 * yy + 8.0 * np.sin(xx / 9.0)).astype(np.float32)
+    i1[:, :8] = i0[:, :8]                                           # some exact ramp left: gradients (4, 4) whatever the warp does there
+    u0 = np.zeros((2, h, w), np.float32)
+    prm = dict(warps=3, max_inner=15, tol_stop=tol_stop)
+    ou, oit, oerr, oxi = oracle.tvl1_global(i0, i1, u0, lam=40.0, theta=0.3, tau=0.125, tol=0.01, warps=3, max_inner=15,
+                                            tol_stop=bool(tol_stop))
+    with F.Context(0) as c:
+        assert c.exact_redos() == 0
+        b = F.Tvl1Batch(c, 1, w, h)
+        try:
+            b.upload(0, i0, i1, u0)
+            iters, errs, ms, launches = b.solve(**prm)
+            assert c.exact_redos() == 1
+            u, xi = b.download(0, want_xi=True)
+            assert list(iters[0]) == list(oit) and bits_equal(errs[0], oerr)
+            assert bits_equal(u, ou), mismatch_report(u, ou)
+            assert bits_equal(xi, oxi), mismatch_report(xi, oxi)
+            b.solve(**prm)                                          # the batch remembers: no second repeat
+            assert c.exact_redos() == 1
+            assert bits_equal(b.download(0), ou)
+            b.upload(0, i0, i1, u0)                                 # new images: the short form is tried again
+            b.solve(**prm)
+            assert c.exact_redos() == 2
+            # normalised images never get there
+            n0, n1 = i0 / np.float32(1500.0), i1 / np.float32(1500.0)
+            b.upload(0, n0, n1, u0)
+            b.solve(**prm)
+            assert c.exact_redos() == 2
+            ou2 = oracle.tvl1_global(n0, n1, u0, lam=40.0, theta=0.3, tau=0.125, tol=0.01, warps=3, max_inner=15,
+                                     tol_stop=bool(tol_stop))[0]
+            assert bits_equal(b.download(0), ou2)
+        finally:
+            b.close()
+
+
+def test_even_integer_theta_takes_the_general_quotient(ctx, oracle):
+    """theta is a divisor too: theta = 6 (an even integer >= 6; no sensible value, but a legal one) selects the general form from
+    the start -- no repeat -- and the result is the checker's."""
+    i0n, i1n, gt = synthetic_pair(128, 96, seed=77, amp=2.0)
+    u0 = (0.5 * gt).astype(np.float32)
+    before = ctx.exact_redos()
+    for theta in (6.0, 5.0, 0.25):
+        gu, git, gerr, gxi, ms = ctx.tvl1_global(i0n, i1n, u0, xi=np.zeros((4, 96, 128), np.float32), theta=theta, warps=2, max_inner=20)
+        ou, oit, oerr, oxi = oracle.tvl1_global(i0n, i1n, u0, lam=40.0, theta=theta, tau=0.125, tol=0.01, warps=2, max_inner=20,
+                                                tol_stop=True)
+        assert list(git) == list(oit) and bits_equal(gu, ou) and bits_equal(gxi, oxi), theta
+    assert ctx.exact_redos() == before
