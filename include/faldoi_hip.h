@@ -152,7 +152,10 @@ int faldoi_tvl1_schedule_query(int npairs, int nx, int ny, const faldoi_tvl1_par
  * per compute unit: every tile's state stays in registers for the whole solve and only the halo is exchanged between
  * workgroups; with tol_stop != 0 the workgroups also take the reference's stop decision themselves, every `chunk` iterations); chunk_launches is then 1, `chunk` the iterations between two exchanges and
  * chunk_kernel_ms that launch's duration.  The environment variable FALDOI_PERSIST=0 selects the per-launch path; results are
- * identical on both. */
+ * identical on both.
+ * Which solves take it: ONE pair whose 64 x 48 tiles (54 x 36 owned pixels each) number at most one per compute unit and at most 256
+ * -- up to about 0.5 Mpixel on a 256-CU device: 1024 x 436 is 247 tiles; a 1280 x 720 frame (480 tiles) and every batch of several
+ * pairs run on the per-launch path, with the same results (faldoi_tvl1_schedule_query answers for any size without a device). */
 int faldoi_tvl1_batch_last_persistent(faldoi_tvl1_batch *b, int *persistent);
 
 /* ---------------------------------------------------------------- primitives (host buffers)
