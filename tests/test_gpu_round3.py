@@ -501,3 +501,18 @@ def test_even_integer_theta_takes_the_general_quotient(ctx, oracle):
                                                 tol_stop=True)
         assert list(git) == list(oit) and bits_equal(gu, ou) and bits_equal(gxi, oxi), theta
     assert ctx.exact_redos() == before
+
+
+def test_general_quotient_instantiations_pass_the_tvl1_families():
+    """Every TV-L1 kernel exists twice (ONCE = true / false).  The suite runs the first; this runs the TV-L1 families of the parity
+    suite -- every tile shape, the persistent kernels in both stop modes, batches -- once more in a child process whose library
+    uses the general instantiations from the start (FALDOI_EXACT_QUOTIENTS=1 is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                        "-p", "no:cacheprovider", "-k", "tvl1 or persist or solve or tile or batch"],
+                       env=dict(os.environ, FALDOI_EXACT_QUOTIENTS="1"), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1500:]
