@@ -344,16 +344,18 @@ static bool tile_supported(int r, int w)
 //     240 tiles on 256 CUs) it is the fastest of the launch-per-chunk schedules -- fewest launches, all CUs busy once
 //     (a static schedule of such a job runs on the persistent kernel instead, pick_persist);
 //   * with more tiles than CUs (batches, large frames) occupancy is no longer the constraint, the halo redundancy and
-//     the overlap between workgroups are: 64x32 tiles of 512 threads (two workgroups per CU, each with its own barriers)
-//     advanced 5 iterations per launch: 114 / 121 / 135 / 144 Gpx*iter/s at 2 / 3 / 4 / 8 pairs per GPU (round 2; the
-//     64x36 tiles of 768 threads used before: 96 / 108 / 106 / 114).
+//     the overlap between workgroups are: two workgroups per CU, each with its own barriers, advanced 5 iterations per launch.
+//     Round 2 chose 64x32 tiles of 512 threads (114 / 121 / 135 / 144 Gpx*iter/s at 2 / 3 / 4 / 8 pairs per GPU; 64x36 tiles of
+//     768 threads: 96 / 108 / 106 / 114).  Round 3: with the one-product quotients the 64x36 kernel needs 73 registers instead of
+//     81, so two of its workgroups fit a CU (6 waves per SIMD), and it is the faster one again: 115 / 136 / 137 / 146 / 154 / 155
+//     Gpx*iter/s at 2 / 3 / 4 / 5 / 6 / 8 pairs against 116 / 123 / 136 / 138 / 145 / 145 for 64x32 (tools, same run, mixed pairs).
 // An explicit params.chunk or FALDOI_TILE=R,NW (tuning aid) overrides the choice.
 static void pick_schedule(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *prm, TileCfg *tc, int *chunk)
 {
     const int S = kTileW - 20;                                  // owned pixels per 64-wide tile at k = 10
     const long tiles_big = (long)((b->nx + S - 1) / S) * ((b->ny + S - 1) / S) * b->npairs;
     const bool small_job = tiles_big <= b->ctx->n_cu;
-    *tc = small_job ? TileCfg{4, 16} : TileCfg{4, 8};
+    *tc = small_job ? TileCfg{4, 16} : TileCfg{3, 12};
     int k = prm->chunk ? prm->chunk : (small_job ? 10 : 5);
     if (const char *s = getenv("FALDOI_TILE")) {
         int r = 0, w = 0;

@@ -34,9 +34,9 @@ def test_schedule_selection_is_host_logic_and_picks_what_was_measured(monkeypatc
     q = F.capi.schedule_query
     assert q(1, 1024, 436, warps=300, max_inner=10, tol_stop=0) == (True, 3, 16, 5, 247)       # BASELINE configs[1]
     assert q(1, 1024, 436) == (True, 3, 16, 5, 247)                                              # the reference's defaults
-    assert q(1, 1024, 436, compute_units=128, tol_stop=0) == (False, 4, 8, 5, 380)               # does not fit half a chip
-    assert q(4, 1024, 436, tol_stop=0) == (False, 4, 8, 5, 4 * 380)                              # BASELINE configs[3] shape
-    assert q(1, 1920, 1080, tol_stop=0)[:4] == (False, 4, 8, 5)                                  # more tiles than CUs
+    assert q(1, 1024, 436, compute_units=128, tol_stop=0) == (False, 3, 12, 5, 323)               # does not fit half a chip
+    assert q(4, 1024, 436, tol_stop=0) == (False, 3, 12, 5, 4 * 323)                              # BASELINE configs[3] shape
+    assert q(1, 1920, 1080, tol_stop=0)[:4] == (False, 3, 12, 5)                                 # more tiles than CUs
     assert q(1, 256, 192, tol_stop=0) == (True, 3, 16, 5, 5 * 6)
     assert q(1, 1024, 436, max_inner=3, tol_stop=0) == (True, 3, 16, 3, 18 * 11)                 # chunk = the iteration bound
     assert q(1, 1024, 436, chunk=16) == (False, 4, 16, 16, 32 * 14)                              # an explicit chunk the tiles cannot host

@@ -42,13 +42,13 @@ def test_config3_per_gpu_slice_four_full_size_pairs(ctx, oracle):
     independently; per-pair iteration counts, errors, flow and duals are bit-equal to the CPU checker.  Then the static
     schedule (BASELINE configs[1]'s shape) for the same batch, 20 warps x 10, two of the pairs against the checker."""
     pairs = _slice_of_four(oracle)
-    assert F.capi.schedule_query(4, W, H)[:4] == (False, 4, 8, 5)          # launch-per-chunk path, 64x32 tiles, k = 5
+    assert F.capi.schedule_query(4, W, H)[:4] == (False, 3, 12, 5)         # launch-per-chunk path, 64x36 tiles, k = 5
     b = F.Tvl1Batch(ctx, 4, W, H)
     try:
         for i, (i0n, i1n, u0) in enumerate(pairs):
             b.upload(i, i0n, i1n, u0)
         iters, errs, ms, launches = b.solve()
-        assert not b.last_persistent() and b.last_schedule() == (4, 8, 5)
+        assert not b.last_persistent() and b.last_schedule() == (3, 12, 5)
         counts = []
         for i, (i0n, i1n, u0) in enumerate(pairs):
             ou, oit, oerr, oxi = oracle.tvl1_global(i0n, i1n, u0)
@@ -63,7 +63,7 @@ def test_config3_per_gpu_slice_four_full_size_pairs(ctx, oracle):
         print("configs[3] slice, reference defaults: %.2f ms for %s iterations, %d launches" % (ms, counts, launches))
 
         iters, errs, ms, launches = b.solve(warps=20, max_inner=10, tol_stop=0)
-        assert not b.last_persistent() and b.last_schedule() == (4, 8, 5) and launches == 40
+        assert not b.last_persistent() and b.last_schedule() == (3, 12, 5) and launches == 40
         assert (iters == 10).all()
         for i in (1, 2):
             i0n, i1n, u0 = pairs[i]

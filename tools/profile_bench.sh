@@ -26,7 +26,7 @@ run fetch --kernel-trace --pmc FETCH_SIZE
 run write --kernel-trace --pmc WRITE_SIZE
 python3 tools/pmc_summary.py --out $OUT/counters.json --label "$TAG: python3 bench.py $ARGS" --chunk-tile "$TILE" --persist-tile "$PTILE" \
     --grid tvl1_persist_kernel=253952 --grid tvl1_chunk_kernel=245760 --grid tvl1_warp_kernel=446464 --grid nl_fused_kernel=458752 \
-    --grid tvl1_chunk_kernel@batch4=778240 --grid tvl1_warp_kernel@batch4=1785856 --tile tvl1_chunk_kernel@batch4=4,8,5,4,1024x436 \
+    --grid tvl1_chunk_kernel@batch4=995328 --grid tvl1_warp_kernel@batch4=1785856 --tile tvl1_chunk_kernel@batch4=3,12,5,4,1024x436 \
     $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/fetch $OUT/write
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 rm -rf $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/fetch $OUT/write
