@@ -516,3 +516,28 @@ def test_general_quotient_instantiations_pass_the_tvl1_families():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1500:]
+
+
+@pytest.mark.parametrize("tol_stop", [0, 1])
+def test_frame_larger_than_the_persistent_launch_takes_the_per_launch_path(ctx, oracle, tol_stop):
+    """One 1280 x 720 pair is 480 tiles of 54 x 36 owned pixels -- more than one per compute unit -- so it cannot run as the one
+    persistent launch (include/faldoi_hip.h, faldoi_tvl1_batch_last_persistent): the library says so through the schedule query,
+    runs it on the launch-per-chunk path with the batches' tile shape, and the result is the CPU checker's."""
+    w, h = 1280, 720
+    assert F.capi.schedule_query(1, w, h, tol_stop=tol_stop)[:4] == (False, 3, 12, 5)
+    i0n, i1n, gt = synthetic_pair(w, h, seed=91, amp=3.0)
+    u0 = (0.5 * gt).astype(np.float32)
+    prm = dict(warps=3, max_inner=12, tol_stop=tol_stop, tol=0.05)
+    b = F.Tvl1Batch(ctx, 1, w, h)
+    try:
+        b.upload(0, i0n, i1n, u0)
+        iters, errs, ms, launches = b.solve(**prm)
+        assert not b.last_persistent() and b.last_schedule() == (3, 12, 5)
+        ou, oit, oerr, oxi = oracle.tvl1_global(i0n, i1n, u0, lam=40.0, theta=0.3, tau=0.125, tol=0.05, warps=3, max_inner=12,
+                                                tol_stop=bool(tol_stop))
+        u, xi = b.download(0, want_xi=True)
+        assert list(iters[0]) == list(oit) and bits_equal(errs[0], oerr)
+        assert bits_equal(u, ou), mismatch_report(u, ou)
+        assert bits_equal(xi, oxi), mismatch_report(xi, oxi)
+    finally:
+        b.close()
