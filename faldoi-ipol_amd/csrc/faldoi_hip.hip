@@ -1449,6 +1449,12 @@ static hipError_t nl_fused_prepare(bool data_l1, int ty) { FALDOI_NL_DISPATCH(nl
 static hipError_t nl_fused_launch(bool data_l1, int ty, hipStream_t s, const NfArgs &a) { FALDOI_NL_DISPATCH(nl_fused_launch_t, s, a); }
 #undef FALDOI_NL_DISPATCH
 
+static bool csad_sort_requested()
+{
+    const char *v = getenv("FALDOI_CSAD_SORT");
+    return v && atoi(v) > 0;
+}
+
 static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float *I1, const float *a, int pd, int nx,
                     int ny, const faldoi_nltvcsad_params *prm, float *u, double *solve_ms)
 {
@@ -1490,9 +1496,13 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
     const float l_t = prm->lambda * prm->theta;                                 // :1659
     // One fused launch per iteration (nltv_fused_kernel.hpp); FALDOI_NL_FUSED=0 selects the two streaming kernels (same bits).
     // (the fused kernel addresses the slab through one buffer resource: below 4 GB, i.e. up to ~7.8 Mpx)
-    const bool fused = !(getenv("FALDOI_NL_FUSED") && atoi(getenv("FALDOI_NL_FUSED")) <= 0) &&
+    bool fused = !(getenv("FALDOI_NL_FUSED") && atoi(getenv("FALDOI_NL_FUSED")) <= 0) &&
                        (unsigned long long)pe * N_COUNT * sizeof(float) < (1ull << 32) &&
                        prm->tau < 0x1p35f;                                      // nl_dual_update's argument for |g| below 2^-60
+    // FALDOI_CSAD_SORT=1: the CSAD selection by the 48-input sorting network per iteration (the round-3 form; streaming kernels only) --
+    // a device-side cross-check of the selection by the warp's rank table (nltv_kernels.hpp), which is the product path.
+    const bool ranked = !csad_sort_requested();
+    if (!ranked) fused = false;
     NfArgs fa;
     int ty = 0;
     if (fused) {
@@ -1501,7 +1511,6 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
         fa.base = base; fa.pe = pe; fa.nx = nx; fa.ny = ny;
         fa.ntx = (nx + kNfW - 1) / kNfW; fa.nty = (ny + ty - 1) / ty;
         fa.cur = 0; fa.tau = prm->tau; fa.l_t = l_t; fa.theta = prm->theta; fa.rtheta = 1.0 / (double)prm->theta;
-        for (int c = 1; c <= kCsSlots; ++c) fa.kl[c - 1] = (float)(kCsSlots + 2 - 2 * c) * l_t;
         HIP_TRY(nl_fused_prepare(data_l1, ty));
     }
     HIP_TRY(hipEventRecord(ctx->ev0, s));
@@ -1509,6 +1518,9 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
                        nx, ny, (size_t)0, (size_t)0, 1);                        // :1690
     for (int w = 0; w < prm->warps; ++w) {
         hipLaunchKernelGGL(nl_warp_kernel, grid, block, 0, s, base, pe, nx, ny, data_l1 ? 1 : 0, fused ? fa.cur : 0);
+        if (!data_l1 && ranked)                                                 // the order of this warp's 48 CSAD terms per pixel
+            hipLaunchKernelGGL(csad_rank_kernel, grid, block, 0, s, base + N_I0 * pe, base + N_I1W * pe, base + N_T1 * pe, base + N_T2 * pe,
+                               reinterpret_cast<unsigned *>(base + N_RK * pe), pe, nx, ny);
         for (int it = 0; it < prm->max_inner; ++it) {                           // :1729 / :1240, no tolerance test
             if (fused) {
                 HIP_TRY(nl_fused_launch(data_l1, ty, s, fa));
@@ -1517,9 +1529,11 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
             }
             hipLaunchKernelGGL(nl_dual_kernel, grid, block, 0, s, base, pe, nx, ny, prm->tau);
             if (data_l1)
-                hipLaunchKernelGGL(nl_primal_kernel<true>, grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);
+                hipLaunchKernelGGL((nl_primal_kernel<true, true>), grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);
+            else if (ranked)
+                hipLaunchKernelGGL((nl_primal_kernel<false, true>), grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);
             else
-                hipLaunchKernelGGL(nl_primal_kernel<false>, grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);
+                hipLaunchKernelGGL((nl_primal_kernel<false, false>), grid, block, 0, s, base, pe, nx, ny, l_t, prm->theta, prm->tau);
         }
         HIP_TRY(hipGetLastError());
     }

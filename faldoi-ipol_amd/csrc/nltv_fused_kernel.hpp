@@ -5,7 +5,7 @@
 // 64 x TY pixels and keeps the new duals of the tile in LDS between the two steps:
 //
 //   stage      ubar (2-pixel ring) and, for the CSAD data term, I0 / I1w (3-pixel ring) into LDS
-//   data       CSAD selection (:1733-1758; neighbourhoods from LDS) or TV-L1 thresholding: v from u
+//   data       CSAD selection (:1733-1758; six probes of the warp's rank table, neighbours from LDS) or TV-L1 thresholding: v from u
 //   dual, p    every thread updates the 24 duals p[s] of its pixel (ofnltv_getD, src/global_faldoi.cpp:1127): new value to HBM,
 //              to LDS and kept in registers; the duals of ring pixels whose slot points INTO the tile ("crossing edges",
 //              ~10 % of the tile's own) are recomputed from the neighbour tile's old values -- nothing else of the ring is needed
@@ -17,14 +17,14 @@
 // HBM (read `cur`, write `1 - cur`; the host flips per iteration).  The per-pixel arithmetic is the two-kernel path's, operation
 // for operation (shared device functions), so results are bit-identical to it and to the CPU checker (tests, fuzz family nltv).
 //
-// LDS: 24 x (TY+4) x 68 floats of duals + the staged planes = 138 KB at TY = 14: one workgroup of 64 x TY threads per CU.
+// LDS: 24 x (TY+4) x 68 floats of duals + the staged planes = 154.5 KB at TY = 16 (of 160): one workgroup of 64 x TY threads per CU.
 #pragma once
 #include "nltv_kernels.hpp"
 
 #pragma clang fp contract(off)
 
 // FALDOI_NFWHATIF (timing-only builds, wrong results; tools/nl_whatif.sh): 1 no data step | 2 no crossing edges | 4 trivial dual
-// arithmetic | 8 no sorting network | 16 no HBM stores of the duals | 32 no quotient in the CSAD terms
+// arithmetic | 16 no HBM stores of the duals
 #ifndef FALDOI_NFWHATIF
 #define FALDOI_NFWHATIF 0
 #endif
@@ -35,7 +35,8 @@ namespace faldoi {
 constexpr int kNfWhatIf = FALDOI_NFWHATIF;
 constexpr int kNfW = 64;                      // tile width: one wavefront per tile row
 constexpr int kNfLW = kNfW + 2 * kNlR;        // 68: LDS row of a dual plane / of ubar (2-pixel ring)
-constexpr int kNfIW = kNfW + 2 * kCsR;        // 70: LDS row of the staged I0 / I1w (3-pixel ring)
+constexpr int kNfIW = kNfW + 8;                // 72: LDS row of the staged I0 / I1w (3-pixel ring, 70 used): a window position byte
+                                              // e = (k+3)*8 + (l+3) of the rank table addresses the row-major tile as 9 e - 8 (e & 7)
 
 template <int TY> struct NfLds {
     float pq[kNlSlots][TY + 2 * kNlR][kNfLW];
@@ -50,8 +51,6 @@ struct NfArgs {
     int cur;                                  // which buffer of the duals / ubar holds the state this iteration reads
     float tau, l_t, theta;
     double rtheta;                            // 1 / theta in double (host), for the exact quotients by theta
-    float kl[kCsSlots];                       // (float)(50 - 2c) * l_t, c = 1..48: the arithmetic progression of the CSAD selection when all
-                                              // 48 neighbours exist (interior tiles); the same fp32 product the kernel would form
 };
 
 // Plane accesses go through ONE buffer resource over the whole slab: the per-lane byte offset of a pixel sits in one VGPR and the
@@ -207,45 +206,69 @@ __device__ __forceinline__ void nf_cross_store_q(NfLds<TY> &L, const NfCrossRegs
         if (cr.at[r] >= 0) (&L.pq[0][0][0])[cr.at[r]] = cr.q[r];
 }
 
-// The dual step of one flow component for the thread's own pixel: 24 slots in batches of kNlBatch (loads of a batch requested
-// together); new dual to HBM, to LDS and kept in preg.  The first component also loads the 24 weights (kept in wreg).
-template <int TY, bool BORDER, int COMP>
-__device__ __forceinline__ void nf_dual_own(NfLds<TY> &L, const NfArgs &a, NfRsrc rs, unsigned pb, int d_old, int d_new, int X0, int Y0, int lx, int ly,
-                                            unsigned i4, float wt, double rwt, float (&wreg)[kNlSlots], float (&preg)[kNlSlots],
-                                            bool (&oks)[kNlSlots])
+// The dual step of one flow component for the thread's own pixel: 24 slots in batches of kNlBatch.  A batch's loads are REQUESTED
+// one batch ahead of its arithmetic (nf_batch_loads / nf_batch_update, interleaved by nl_fused_body): a workgroup's sixteen waves
+// run through the phases in step (barriers), so a load that is waited for right after its request costs its whole latency on every
+// wave at once -- round 3's kernel spent about half of a tile's time that way.  New dual to HBM, to LDS and kept in preg; the first
+// component also loads the 24 weights (kept in wreg).
+struct NfBatch {
+    float p[kNlBatch], w[kNlBatch];
+};
+template <int COMP>
+__device__ __forceinline__ void nf_batch_loads(NfRsrc rs, unsigned pb, int d_old, int s0, unsigned i4, NfBatch &b)
 {
-    // pb = bytes per plane; d_old / d_new = first plane of the component's 24 duals in the buffer read / written
-    const int x = X0 + lx, y = Y0 + ly;
+    // pb = bytes per plane; d_old = first plane of the component's 24 duals in the buffer that is read
+#pragma unroll
+    for (int q = 0; q < kNlBatch; ++q) {
+        b.p[q] = nf_ld(rs, (unsigned)(d_old + s0 + q) * pb, i4);
+        if (COMP == 0) b.w[q] = nf_ld(rs, (unsigned)(N_W + s0 + q) * pb, i4);
+    }
+}
+template <int TY, bool BORDER, int COMP>
+__device__ __forceinline__ void nf_batch_update(NfLds<TY> &L, const NfArgs &a, NfRsrc rs, unsigned pb, int d_new, int s0, int x, int y, int lx, int ly,
+                                                unsigned i4, float wt, double rwt, const NfBatch &b, float (&wreg)[kNlSlots],
+                                                float (&preg)[kNlSlots], bool (&oks)[kNlSlots])
+{
     const float ai = L.ub[COMP][ly + kNlR][lx + kNlR];
+    // (a slot that leaves the image is evaluated like the others -- its weight and its neighbour's ubar read as 0 -- but never
+    // stored: such slots keep their duals, :1145, and the divergence skips them)
+    float pb6[kNlBatch], wb6[kNlBatch], nb6[kNlBatch];
 #pragma unroll
-    for (int s0 = 0; s0 < kNlSlots; s0 += kNlBatch) {
-#pragma unroll
-        for (int s = s0; s < s0 + kNlBatch; ++s) {
-            preg[s] = nf_ld(rs, (unsigned)(d_old + s) * pb, i4);
-            if (COMP == 0) {
-                const int k = nl_slot_k(s), l = nl_slot_l(s);
-                wreg[s] = nf_ld(rs, (unsigned)(N_W + s) * pb, i4);
-                oks[s] = !BORDER || (x + l >= 0 && x + l < a.nx && y + k >= 0 && y + k < a.ny);
-            }
+    for (int q = 0; q < kNlBatch; ++q) {
+        const int s = s0 + q;
+        if (COMP == 0) {
+            const int k = nl_slot_k(s), l = nl_slot_l(s);
+            wreg[s] = b.w[q];
+            oks[s] = !BORDER || (x + l >= 0 && x + l < a.nx && y + k >= 0 && y + k < a.ny);
         }
-        // (a slot that leaves the image is evaluated like the others -- its weight and its neighbour's ubar read as 0 -- but never
-        // stored: such slots keep their duals, :1145, and the divergence skips them)
-        float pb6[kNlBatch], wb6[kNlBatch], nb6[kNlBatch];
+        pb6[q] = b.p[q];
+        wb6[q] = wreg[s];
+        nb6[q] = L.ub[COMP][ly + kNlR + nl_slot_k(s)][lx + kNlR + nl_slot_l(s)];
+    }
+    nl_dual_update_n<kNlBatch>(pb6, wb6, ai, nb6, wt, rwt, a.tau);
 #pragma unroll
-        for (int q = 0; q < kNlBatch; ++q) {
-            const int s = s0 + q;
-            pb6[q] = preg[s];
-            wb6[q] = wreg[s];
-            nb6[q] = L.ub[COMP][ly + kNlR + nl_slot_k(s)][lx + kNlR + nl_slot_l(s)];
-        }
-        nl_dual_update_n<kNlBatch>(pb6, wb6, ai, nb6, wt, rwt, a.tau);
+    for (int q = 0; q < kNlBatch; ++q) {
+        const int s = s0 + q;
+        if (!(kNfWhatIf & 16) && (!BORDER || oks[s])) nf_st(rs, (unsigned)(d_new + s) * pb, i4, pb6[q]);
+        L.pq[s][ly + kNlR][lx + kNlR] = pb6[q];
+        preg[s] = pb6[q];
+    }
+}
+// Batches 1..3 of a component (batch 0 was requested by the caller, earlier): request the next batch, then update the current one.
+template <int TY, bool BORDER, int COMP>
+__device__ __forceinline__ void nf_dual_own(NfLds<TY> &L, const NfArgs &a, NfRsrc rs, unsigned pb, int d_old, int d_new, int x, int y, int lx, int ly,
+                                            unsigned i4, bool in, float wt, double rwt, NfBatch &b0, float (&wreg)[kNlSlots],
+                                            float (&preg)[kNlSlots], bool (&oks)[kNlSlots])
+{
+    NfBatch nb[kNlSlots / kNlBatch];
+    nb[0] = b0;
 #pragma unroll
-        for (int q = 0; q < kNlBatch; ++q) {
-            const int s = s0 + q;
-            if (!(kNfWhatIf & 16) && (!BORDER || oks[s])) nf_st(rs, (unsigned)(d_new + s) * pb, i4, pb6[q]);
-            L.pq[s][ly + kNlR][lx + kNlR] = pb6[q];
-            preg[s] = pb6[q];
+    for (int k = 0; k < kNlSlots / kNlBatch; ++k) {
+        if (k + 1 < kNlSlots / kNlBatch) {
+            nf_batch_loads<COMP>(rs, pb, d_old, (k + 1) * kNlBatch, i4, nb[k + 1]);
+            __builtin_amdgcn_sched_barrier(0);                           // (the requests stay ahead of the arithmetic below)
         }
+        if (in) nf_batch_update<TY, BORDER, COMP>(L, a, rs, pb, d_new, k * kNlBatch, x, y, lx, ly, i4, wt, rwt, nb[k], wreg, preg, oks);
     }
 }
 
@@ -265,39 +288,67 @@ __device__ __forceinline__ float nf_divergence(const NfLds<TY> &L, int lx, int l
     return d;
 }
 
-// csad_select of nltv_kernels.hpp with the 7x7 neighbourhoods of I0 and I1w read from the staged LDS tiles.
+// csad_select_ranked of nltv_kernels.hpp with the neighbours of I0 and I1w read from the staged LDS tiles: six probes per pixel.
+template <int TY> struct NfCsadFetch {
+    const float *im;          // &L.im[0][ly][lx]: window position (k, l) = (-3, -3) of this pixel
+    __device__ __forceinline__ void operator()(unsigned e, bool, float &a0, float &a1) const
+    {
+        // (a probe that is not live carries a byte of the table all the same: 0 <= e <= 54, inside the staged tile)
+        const unsigned off = 9u * e - 8u * (e & 7u);
+        a0 = im[off];
+        a1 = im[off + (TY + 2 * kCsR) * kNfIW];
+    }
+};
 template <int TY, bool BORDER>
-__device__ __forceinline__ float nf_csad_select(const NfLds<TY> &L, int lx, int ly, int x, int y, int nx, int ny, float t1, float t2,
-                                                float r, float sg, double rsg, float l_t, const float (&kl)[kCsSlots])
+__device__ __forceinline__ float nf_csad_select(const NfLds<TY> &L, const unsigned (&rk)[kCsRankWords], int lx, int ly, int x, int y, int nx,
+                                                int ny, float t1, float t2, float r, float sg, double rsg, float l_t)
 {
     const float i0 = L.im[0][ly + kCsR][lx + kCsR], i1w = L.im[1][ly + kCsR][lx + kCsR];
-    float A[kCsSlots];
-    int n = 0;
+    const int n = BORDER ? csad_valid_count(x, y, nx, ny) : kCsSlots;
+    return csad_select_ranked<!BORDER>(rk, n, NfCsadFetch<TY>{ &L.im[0][ly][lx] }, i0, i1w, t1, t2, r, sg, rsg, l_t);
+}
+
+typedef float nf_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned nf_u4 __attribute__((ext_vector_type(4)));
+
+// One staged quad: four consecutive pixels of a row of the tile's footprint, one 16-byte load (4-byte aligned: gfx950 takes it),
+// one 16-byte LDS write (rows of 68 / 72 floats keep the quads aligned).  Pixels outside the image become 0.
+struct NfQuad {
+    nf_f4 v;
+    int lds;              // float index of the quad inside its LDS array, -1: this thread stages nothing
+};
+template <int ROWS, int ROW_FLOATS, int RING>
+__device__ __forceinline__ NfQuad nf_stage_load(NfRsrc rs, unsigned pb, int plane0, int t, int X0, int Y0, int nx, int ny)
+{
+    constexpr int Q = ROW_FLOATS / 4, n = 2 * ROWS * Q;
+    const int comp = t / (ROWS * Q), rem = t - comp * (ROWS * Q), ry = rem / Q, rq = rem - ry * Q;
+    const int gx = X0 - RING + 4 * rq, gy = Y0 - RING + ry;
+    const bool row = t < n && gy >= 0 && gy < ny && gx < nx;
+    // The tile's first quad of a row starts RING pixels left of the image when the tile does (X0 = 0): it is loaded from column 0 and
+    // shifted -- on row 0 of the slab's first plane the unshifted address would lie before the buffer, and the whole load returns 0.
+    // A quad that straddles the image's right edge reads the next row's start (or, at the slab's very end, outside the buffer
+    // resource, which returns 0); those components are zeroed below.
+    const bool lead = gx < 0;                                          // then gx == -RING
+    const unsigned off = row ? (unsigned)(plane0 + comp) * pb + 4u * (unsigned)(gy * nx + (lead ? 0 : gx)) : 0u;
+    const nf_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0u, 0);
+    NfQuad q;
 #pragma unroll
-    for (int s = 0; s < kCsSlots; ++s) {
-        const int c = s < 24 ? s : s + 1;
-        const int k = c / 7 - kCsR, l = c % 7 - kCsR;
-        const bool ok = !BORDER || (x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny);
-        const float a0 = L.im[0][ly + kCsR + k][lx + kCsR + l], a1 = L.im[1][ly + kCsR + k][lx + kCsR + l];
-        // (an out-of-image slot reads the staged zeros; its term is discarded below, as the two-kernel path discards its own)
-        const float bs = (kNfWhatIf & 32) ? (i0 - a0 - i1w + a1 + t1 + t2) * sg : div_by(i0 - a0 - i1w + a1 + t1 + t2, sg, rsg);   // :1716-1717
-        A[s] = ok ? -(bs - r) : __builtin_inff();
-        n += ok ? 1 : 0;
+    for (int j = 0; j < 4; ++j) {
+        // (elements are copied to scalars first: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 for
+        // every index with this compiler -- found in the ISA, where the 16-byte load had shrunk to one dword)
+        const unsigned e = raw[j], es = raw[j >= RING ? j - RING : 0];
+        const bool ok = row && (lead ? j >= RING && j - RING < nx : gx + j < nx);
+        q.v[j] = ok ? __uint_as_float(lead ? es : e) : 0.0f;
     }
-    if (!(kNfWhatIf & 8)) sort48(A);
-    float m = __builtin_inff();
-#pragma unroll
-    for (int c = 1; c <= kCsSlots; ++c) {
-        const float bv = !BORDER ? kl[c - 1] * sg : (c <= n + 1) ? (float)(n + 2 - 2 * c) * l_t * sg : __builtin_inff();
-        m = __builtin_fminf(m, __builtin_fmaxf(A[c - 1], bv));
-    }
-    return m;
+    q.lds = t < n ? (comp * ROWS + ry) * ROW_FLOATS + 4 * rq : -1;
+    return q;
 }
 
 template <bool DATA_L1, int TY, bool BORDER>
 __device__ __forceinline__ void nl_fused_body(const NfArgs &a, NfLds<TY> &L, int X0, int Y0)
 {
     constexpr int NT = kNfW * TY;
+    static_assert(2 * (TY + 2 * kNlR) * (kNfLW / 4) <= NT && 2 * (TY + 2 * kCsR) * (kNfIW / 4) <= NT, "one staged quad per thread");
     const int nx = a.nx, ny = a.ny;
     const int t = threadIdx.x, lx = t & 63, ly = t >> 6;
     const int x = X0 + lx, y = Y0 + ly;
@@ -309,75 +360,77 @@ __device__ __forceinline__ void nl_fused_body(const NfArgs &a, NfLds<TY> &L, int
     const int ub_old = cur ? N_UBB1 : N_UB1, ub_new = cur ? N_UB1 : N_UBB1;          // two consecutive planes each
     const int p_old = cur ? N_PB : N_P, p_new = cur ? N_P : N_PB, q_old = cur ? N_QB : N_Q, q_new = cur ? N_Q : N_QB;
 
-    // ---- stage ubar (ring 2) and I0 / I1w (ring 3); outside the image: 0 (never used in an accepted term)
-    {
-        constexpr int RW = kNfLW, RH = TY + 2 * kNlR, n_ub = 2 * RH * RW;
-#pragma unroll
-        for (int q = 0; q < (n_ub + NT - 1) / NT; ++q) {
-            const int e = t + q * NT;
-            const int comp = e / (RH * RW), rem = e - comp * (RH * RW), ry = rem / RW, rx = rem - ry * RW;
-            const int gx = X0 - kNlR + rx, gy = Y0 - kNlR + ry;
-            const bool ok = e < n_ub && gx >= 0 && gx < nx && gy >= 0 && gy < ny;
-            const float v = nf_ld(rs, 0u, ok ? (unsigned)(ub_old + comp) * pb + 4u * (unsigned)(gy * nx + gx) : 0u);
-            if (e < n_ub) L.ub[comp][ry][rx] = ok ? v : 0.0f;
-        }
-        if (!DATA_L1) {
-            constexpr int IW = kNfIW, IH = TY + 2 * kCsR, n_im = 2 * IH * IW;
-#pragma unroll
-            for (int q = 0; q < (n_im + NT - 1) / NT; ++q) {
-                const int e = t + q * NT;
-                const int comp = e / (IH * IW), rem = e - comp * (IH * IW), ry = rem / IW, rx = rem - ry * IW;
-                const int gx = X0 - kCsR + rx, gy = Y0 - kCsR + ry;
-                const bool ok = e < n_im && gx >= 0 && gx < nx && gy >= 0 && gy < ny;
-                const float v = nf_ld(rs, 0u, ok ? (unsigned)(comp ? N_I1W : N_I0) * pb + 4u * (unsigned)(gy * nx + gx) : 0u);
-                if (e < n_im) L.im[comp][ry][rx] = ok ? v : 0.0f;
-            }
-        }
+    // ---- every load that does not depend on LDS is requested before anything is waited for (a thread outside the image reads
+    // pixel 0 and uses nothing of it): the staged rings first (they are needed first, and loads return in order), then the pixel's
+    // own values, the warp's rank table, and the first batch of duals and weights
+    const NfQuad sq_ub = nf_stage_load<TY + 2 * kNlR, kNfLW, kNlR>(rs, pb, ub_old, t, X0, Y0, nx, ny);
+    NfQuad sq_im;
+    sq_im.lds = -1;
+    if (!DATA_L1) {
+        // (the helper reads plane0 + component; I0 and I1w are not neighbouring planes, so plane0 is chosen per component)
+        constexpr int IH = TY + 2 * kCsR;
+        const int comp = t / (IH * (kNfIW / 4));
+        sq_im = nf_stage_load<IH, kNfIW, kCsR>(rs, pb, comp ? N_I1W - 1 : N_I0, t, X0, Y0, nx, ny);
     }
     const float wt = nf_ld(rs, (unsigned)N_WT * pb, i4);
+    const float u1k = nf_ld(rs, (unsigned)N_U1 * pb, i4), u2k = nf_ld(rs, (unsigned)N_U2 * pb, i4);
+    const float grad = nf_ld(rs, (unsigned)N_GRAD * pb, i4);
+    const float ixw = nf_ld(rs, (unsigned)N_I1WX * pb, i4), iyw = nf_ld(rs, (unsigned)N_I1WY * pb, i4);
+    float c0 = 0.0f, c1 = 0.0f;                    // NLTV-L1: rho_c; NLTV-CSAD: the two warp-start products inside b
+    unsigned rk[kCsRankWords];
+    if (DATA_L1) {
+        c0 = nf_ld(rs, (unsigned)N_I1W * pb, i4);
+    } else {
+        c0 = nf_ld(rs, (unsigned)N_T1 * pb, i4);
+        c1 = nf_ld(rs, (unsigned)N_T2 * pb, i4);
+#pragma unroll
+        for (int w = 0; w < kCsRankWords; ++w) rk[w] = __builtin_amdgcn_raw_buffer_load_b32(rs, i4, (unsigned)(N_RK + w) * pb, 0);
+    }
+    NfBatch bp0;
+    nf_batch_loads<0>(rs, pb, p_old, 0, i4, bp0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- stage ubar (ring 2) and I0 / I1w (ring 3)
+    if (sq_ub.lds >= 0) *reinterpret_cast<nf_f4 *>(&L.ub[0][0][0] + sq_ub.lds) = sq_ub.v;
+    if (!DATA_L1 && sq_im.lds >= 0) *reinterpret_cast<nf_f4 *>(&L.im[0][0][0] + sq_im.lds) = sq_im.v;
     const double rwt = recip_f64(wt);            // wt > 0 (every pixel has valid neighbours): shared by 48 quotients
     __syncthreads();
 
-    // ---- data step (nl_primal_kernel of nltv_kernels.hpp, first half): v from u and the warp's constants -- arithmetic on LDS and
-    // six values of the pixel, independent of the duals.  It runs first: its 48 sorted terms are dead before the 48 weight / dual
-    // registers come alive.  (Measured and dropped: running it last on every second tile, chessboard-wise, so that half of the CUs
-    // compute while the other half stream the dual planes -- no faster; requesting a phase's 48 loads at once -- slower.)
-    float u1k = 0.0f, u2k = 0.0f, v1 = 0.0f, v2 = 0.0f;
-    if (in) {
-        u1k = nf_ld(rs, (unsigned)N_U1 * pb, i4);
-        u2k = nf_ld(rs, (unsigned)N_U2 * pb, i4);
-        const float grad = nf_ld(rs, (unsigned)N_GRAD * pb, i4);
-        v1 = u1k;                                                        // :1735-1736
-        v2 = u2k;
-        if (DATA_L1) {
-            const float ixw = nf_ld(rs, (unsigned)N_I1WX * pb, i4), iyw = nf_ld(rs, (unsigned)N_I1WY * pb, i4);
-            threshold_step(nf_ld(rs, (unsigned)N_I1W * pb, i4), ixw, iyw, grad, recip_f64(grad), u1k, u2k, a.l_t, v1, v2);
-        } else if (!(kNfWhatIf & 1) && !(grad < grad_zero_bound())) {
-            const float ixw = nf_ld(rs, (unsigned)N_I1WX * pb, i4), iyw = nf_ld(rs, (unsigned)N_I1WY * pb, i4);
-            // quotients by sg (>= 1e-4), wt and theta below: div_by returns the IEEE quotient's bits for a finite numerator and a
-            // finite divisor > 0 (faldoi_device.hpp), with the reciprocal shared
-            const float sg = __builtin_sqrtf(grad);
-            const double rsg = recip_f64(sg);
-            const float r = div_by(ixw * u1k + iyw * u2k, sg, rsg);
-            const float m = nf_csad_select<TY, BORDER>(L, lx, ly, x, y, nx, ny, nf_ld(rs, (unsigned)N_T1 * pb, i4),
-                                                       nf_ld(rs, (unsigned)N_T2 * pb, i4), r, sg, rsg, a.l_t, a.kl);
-            v1 = u1k - div_by(ixw * m, sg, rsg);                         // :1756-1757
-            v2 = u2k - div_by(iyw * m, sg, rsg);
-        }
-        asm volatile("" : "+v"(v1), "+v"(v2));                           // (keeps the scheduler from moving the step into the dual phases)
+    // ---- data step (nl_primal_kernel of nltv_kernels.hpp, first half): v from u and the warp's constants -- six probes of the
+    // staged tiles (CSAD) or the thresholding (L1); the first batch of the dual step is in flight meanwhile
+    float v1 = u1k, v2 = u2k;                                             // :1735-1736
+    if (DATA_L1) {
+        threshold_step(c0, ixw, iyw, grad, recip_f64(grad), u1k, u2k, a.l_t, v1, v2);
+    } else if (!(kNfWhatIf & 1) && wave_any(!(grad < grad_zero_bound()))) {
+        // quotients by sg (>= 1e-4), wt and theta below: div_by returns the IEEE quotient's bits for a finite numerator and a
+        // finite divisor > 0 (faldoi_device.hpp), with the reciprocal shared.  (A pixel below the bound keeps v = u; its lanes
+        // evaluate the step on sg = 1 and discard it.)
+        const bool live = !(grad < grad_zero_bound());
+        const float sg = live ? __builtin_sqrtf(grad) : 1.0f;
+        const double rsg = recip_f64(sg);
+        const float r = div_by(ixw * u1k + iyw * u2k, sg, rsg);
+        const float m = nf_csad_select<TY, BORDER>(L, rk, lx, ly, x, y, nx, ny, c0, c1, r, sg, rsg, a.l_t);
+        const float w1 = u1k - div_by(ixw * m, sg, rsg);                  // :1756-1757
+        const float w2 = u2k - div_by(iyw * m, sg, rsg);
+        v1 = live ? w1 : v1;
+        v2 = live ? w2 : v2;
     }
+    asm volatile("" : "+v"(v1), "+v"(v2));                               // (keeps the scheduler from moving the step into the dual phases)
     __builtin_amdgcn_sched_barrier(0);
 
     float wreg[kNlSlots], preg[kNlSlots];
     bool oks[kNlSlots];
     NfCrossRegs<TY> cr;
     if (!(kNfWhatIf & 2)) nf_cross_loads<TY>(a, rs, pb, p_old, q_old, X0, Y0, cr);       // in flight while the own slots are computed
-    if (in) nf_dual_own<TY, BORDER, 0>(L, a, rs, pb, p_old, p_new, X0, Y0, lx, ly, i4, wt, rwt, wreg, preg, oks);
+    nf_dual_own<TY, BORDER, 0>(L, a, rs, pb, p_old, p_new, x, y, lx, ly, i4, in, wt, rwt, bp0, wreg, preg, oks);
+    NfBatch bq0;
+    nf_batch_loads<1>(rs, pb, q_old, 0, i4, bq0);                        // the second component's first batch: in flight across the
+    __builtin_amdgcn_sched_barrier(0);                                   // crossing edges, two barriers and the first divergence
     if (!(kNfWhatIf & 2)) nf_cross_compute<TY>(L, a, X0, Y0, cr);
     __syncthreads();
     float dp = in ? nf_divergence<TY, BORDER>(L, lx, ly, wreg, preg, oks) : 0.0f;
     __syncthreads();
-    if (in) nf_dual_own<TY, BORDER, 1>(L, a, rs, pb, q_old, q_new, X0, Y0, lx, ly, i4, wt, rwt, wreg, preg, oks);
+    nf_dual_own<TY, BORDER, 1>(L, a, rs, pb, q_old, q_new, x, y, lx, ly, i4, in, wt, rwt, bq0, wreg, preg, oks);
     if (!(kNfWhatIf & 2)) nf_cross_store_q<TY>(L, cr);
     __syncthreads();
     if (!in) return;

@@ -36,7 +36,8 @@ enum NlPlane {
     N_UBB1, N_UBB2,
     N_PB,                                  // 24 planes
     N_QB = N_PB + kNlSlots,                // 24 planes
-    N_COUNT = N_QB + kNlSlots
+    N_RK = N_QB + kNlSlots,                // 12 planes of packed bytes: the CSAD terms' order of this warp (csad_rank_kernel)
+    N_COUNT = N_RK + 12
 };
 
 // Per-warp: three bicubic warps (border_out = true), grad = I1wx^2 + I1wy^2, ubar = u (:1694-1725)
@@ -213,13 +214,187 @@ __device__ __forceinline__ float csad_select(const float *I0, const float *I1w, 
     return m;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same selection WITHOUT a sort per iteration (round 4).
+//
+// Within one warp the 48 CSAD terms b_s are constants (I0, I1w and the two warp-start products do not change), and every
+// iteration sorts A_s = -(b_s - r) with an r common to the 48 slots: x -> -fl(x - r) is monotone, so the ORDER of A is the
+// order of b (descending) for the whole warp.  csad_rank_kernel sorts once per warp and stores, per pixel, which slot holds
+// rank 0, 1, ... (48 bytes).  With the order known the selection is a search, not a sort: sorted A is non-decreasing,
+// C_rho = (n - 2 rho) l_t sg is strictly decreasing, so T_rho = max(A_(rho), C_rho) falls (= C_rho) while A_(rho) < C_rho and
+// rises (= A_(rho)) afterwards, and  min_c max(A[c-1], B[n+1-c]) = min_rho T_rho  sits at the crossing: a lower-bound search
+// over rho with steps 32, 16, ..., 1 probes six ranks; the largest probed rank with A < C is rho* - 1 and the smallest probed
+// one without is rho*, every other probed T is no smaller, so the minimum over the six probed T IS the minimum over all 48.
+// Six CSAD terms are evaluated per pixel and iteration instead of 48, and no network (1 500 -> ~200 vector instructions).
+// "<" and max / min are taken in the hardware's total order (v_max_f32 / v_min_f32: -0 before +0) exactly as the sorting
+// network did, so the result has the same bits as csad_select for every non-NaN input (a probe counts as "A < C" when
+// max(A, C) is not A itself) -- checked on the device against the network form (FALDOI_CSAD_SORT=1 keeps it selectable on the
+// streaming kernels) and against the CPU checker, which sorts like the reference.
+//
+// Table layout (12 dwords per pixel, plane w = dword w): the search visits rank (2p+1) step - 1 at the level with that step,
+// p = the path taken so far; a level's candidates lie together so that one v_perm_b32 picks the byte:
+//   dwords 0-1: level 4 (ranks 3, 11, .., 43), then level 2 (15, 47)      dword 2: level 3 (7, 23, 39), then level 1 (31)
+//   dwords 3-5: level 5 (ranks 1, 5, .., 45)                               dwords 6-11: level 6 (ranks 0, 2, .., 46)
+// A byte is the slot's window position (k+3)*8 + (l+3).  Ranks >= n (slots outside the image) hold 0; a probe beyond n is
+// not evaluated ("guard"), its address is still a legal one.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCsRankWords = 12;
+__device__ constexpr unsigned char kCsRankOfByte[4 * kCsRankWords] = {
+    3, 11, 19, 27, 35, 43, 15, 47,   7, 23, 39, 31,
+    1, 5, 9, 13, 17, 21, 25, 29, 33, 37, 41, 45,
+    0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46,
+};
+__device__ __forceinline__ int csad_order_key(float v)      // integer order == total order of the floats (-0 < +0)
+{
+    const int b = __builtin_bit_cast(int, v);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ int csad_valid_count(int x, int y, int nx, int ny)      // neighbours of the 7x7 window inside the image
+{
+    const int cx = (x < kCsR ? x : kCsR) + (nx - 1 - x < kCsR ? nx - 1 - x : kCsR) + 1;
+    const int cy = (y < kCsR ? y : kCsR) + (ny - 1 - y < kCsR ? ny - 1 - y : kCsR) + 1;
+    return cx * cy - 1;
+}
+
+// Once per warp, after the warp kernel (it needs the whole I1w plane): order of the numerators
+//   i0 - I0[pos_s] - i1w + I1w[pos_s] + t1 + t2     (:1716-1717 / :1529-1530 before the division by sg > 0: same order as b)
+// descending, by the 48-input network on (key, position byte) pairs; equal keys give equal A, so their order is immaterial.
+__global__ __launch_bounds__(256) void csad_rank_kernel(const float *__restrict__ I0, const float *__restrict__ I1w,
+                                                        const float *__restrict__ T1, const float *__restrict__ T2,
+                                                        unsigned *__restrict__ rk, size_t pe, int nx, int ny)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nx * ny) return;
+    const int y = i / nx, x = i - y * nx;
+    const float i0 = I0[i], i1w = I1w[i], t1 = T1[i], t2 = T2[i];
+    int key[kCsSlots];
+    unsigned pay[kCsSlots];
+#pragma unroll
+    for (int s0 = 0; s0 < kCsSlots; s0 += kCsBatch) {
+        float a0[kCsBatch], a1[kCsBatch];
+        bool ok[kCsBatch];
+#pragma unroll
+        for (int q = 0; q < kCsBatch; ++q) {
+            const int s = s0 + q, c = s < 24 ? s : s + 1;
+            const int k = c / 7 - kCsR, l = c % 7 - kCsR;
+            ok[q] = x + l >= 0 && x + l < nx && y + k >= 0 && y + k < ny;
+            const int pos = ok[q] ? i + k * nx + l : i;
+            a0[q] = I0[pos];
+            a1[q] = I1w[pos];
+        }
+#pragma unroll
+        for (int q = 0; q < kCsBatch; ++q) {
+            const int s = s0 + q, c = s < 24 ? s : s + 1;
+            const int k = c / 7 - kCsR, l = c % 7 - kCsR;
+            const float num = i0 - a0[q] - i1w + a1[q] + t1 + t2;
+            key[s] = ok[q] ? csad_order_key(num) : (int)0x80000000;            // below every non-NaN key: sorts last
+            pay[s] = ok[q] ? (unsigned)((k + kCsR) * 8 + (l + kCsR)) : 0u;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 384; ++c) {                                           // descending: the larger key to the lower index
+        const int a = kSort48[c].a, b = kSort48[c].b;
+        const bool sw = key[a] < key[b];
+        const int ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];
+        const unsigned pa = sw ? pay[b] : pay[a], pb = sw ? pay[a] : pay[b];
+        key[a] = ka; key[b] = kb; pay[a] = pa; pay[b] = pb;
+    }
+#pragma unroll
+    for (int w = 0; w < kCsRankWords; ++w) {
+        const unsigned v = pay[kCsRankOfByte[4 * w]] | (pay[kCsRankOfByte[4 * w + 1]] << 8) | (pay[kCsRankOfByte[4 * w + 2]] << 16) |
+                           (pay[kCsRankOfByte[4 * w + 3]] << 24);
+        rk[(size_t)w * pe + i] = v;
+    }
+}
+
+// The byte of the level's candidate p (see the layout above).  One past a level's last candidate (the path of a pixel whose
+// every term lies below the progression) still returns a byte of the table.
+__device__ __forceinline__ unsigned csad_perm(unsigned hi, unsigned lo, unsigned sel)      // byte sel (0..7) of {hi, lo}
+{
+    return __builtin_amdgcn_perm(hi, lo, sel | 0x0c0c0c00u);
+}
+template <int LEVEL>
+__device__ __forceinline__ unsigned csad_rank_byte(const unsigned (&d)[kCsRankWords], unsigned p)
+{
+    if (LEVEL == 1) return d[2] >> 24;
+    if (LEVEL == 2) return csad_perm(d[1], d[0], p + 6u);
+    if (LEVEL == 3) return csad_perm(d[2], d[2], p);
+    if (LEVEL == 4) return csad_perm(d[1], d[0], p);
+    if (LEVEL == 5) {
+        const unsigned sel = p & 7u;
+        const unsigned a = csad_perm(d[4], d[3], sel), b = csad_perm(d[3], d[5], sel);
+        return p < 8u ? a : b;
+    }
+    const unsigned sel = p & 7u;
+    const unsigned a = csad_perm(d[7], d[6], sel), b = csad_perm(d[9], d[8], sel), c = csad_perm(d[11], d[10], sel);
+    return p < 8u ? a : (p < 16u ? b : c);
+}
+
+// fetch(e, live, a0, a1): I0 and I1w of the neighbour at window position byte e (live = false: any legal address, value unused).
+// ALL48: every pixel this instantiation sees has its 48 neighbours (n == 48, guards are constants of the level).
+template <bool ALL48, class Fetch>
+__device__ __forceinline__ float csad_select_ranked(const unsigned (&d)[kCsRankWords], int n, Fetch fetch, float i0, float i1w,
+                                                    float t1, float t2, float r, float sg, double rsg, float l_t)
+{
+    float m = __builtin_inff();
+    unsigned p = 0u;
+#define FALDOI_CSAD_LEVEL(LEVEL, STEP)                                                                                         \
+    {                                                                                                                          \
+        /* rank probed: rho = (2p+1) STEP - 1; it exists iff (2p+1) STEP <= n */                                               \
+        const bool live = ALL48 ? (STEP >= 16 || p <= (unsigned)((48 - STEP) / (2 * STEP)))                                    \
+                                : (int)((2u * p + 1u) * (unsigned)STEP) <= n;                                                 \
+        const unsigned e = csad_rank_byte<LEVEL>(d, p);                                                                        \
+        float a0, a1;                                                                                                          \
+        fetch(e, live, a0, a1);                                                                                                \
+        const float bs = div_by(i0 - a0 - i1w + a1 + t1 + t2, sg, rsg);                  /* :1716-1717 / :1529-1530 */         \
+        const float A = live ? -(bs - r) : __builtin_inff();                              /* :1741-1742 */                     \
+        const int coef = (n + 2 - 2 * STEP) - 4 * STEP * (int)p;                          /* n - 2 rho */                      \
+        const float C = (float)coef * l_t * sg;                                           /* :1747 */                          \
+        const float T = __builtin_fmaxf(A, C);                                                                                 \
+        m = __builtin_fminf(m, T);                                                                                             \
+        p = 2u * p + (__builtin_bit_cast(unsigned, T) != __builtin_bit_cast(unsigned, A) ? 1u : 0u);                           \
+    }
+    FALDOI_CSAD_LEVEL(1, 32)
+    FALDOI_CSAD_LEVEL(2, 16)
+    FALDOI_CSAD_LEVEL(3, 8)
+    FALDOI_CSAD_LEVEL(4, 4)
+    FALDOI_CSAD_LEVEL(5, 2)
+    FALDOI_CSAD_LEVEL(6, 1)
+#undef FALDOI_CSAD_LEVEL
+    return m;
+}
+
+// Neighbours from the planes themselves (streaming kernels)
+struct CsadFetchGlobal {
+    const float *I0, *I1w;
+    int i, nx;
+    __device__ __forceinline__ void operator()(unsigned e, bool live, float &a0, float &a1) const
+    {
+        const int pos = live ? i + ((int)(e >> 3) - kCsR) * nx + ((int)(e & 7u) - kCsR) : i;
+        a0 = I0[pos];
+        a1 = I1w[pos];
+    }
+};
+__device__ __forceinline__ float csad_select_by_ranks(const float *I0, const float *I1w, const unsigned *rk, size_t pe, int i, int x, int y,
+                                                      int nx, int ny, float t1, float t2, float r, float sg, float l_t)
+{
+    unsigned d[kCsRankWords];
+#pragma unroll
+    for (int w = 0; w < kCsRankWords; ++w) d[w] = rk[(size_t)w * pe + i];
+    const double rsg = recip_f64(sg);
+    const int n = csad_valid_count(x, y, nx, ny);
+    return csad_select_ranked<false>(d, n, CsadFetchGlobal{ I0, I1w, i, nx }, I0[i], I1w[i], t1, t2, r, sg, rsg, l_t);
+}
+
 // Data step (:1733-1758) + non-local divergence (:1056-1079) + ofnltv_getP (:1090-1120) + relaxation.
 // The data step needs the element of index n+1 (0-based; `it/2+1` with it = 2n+1, sic) of the
 // ascending sort of  A = { -(b_s - r) : valid s }  united with  B = { (n-2j)*l_t*sg : j = 0..n }.
 // A is sorted in registers (invalid slots = +inf); B is an arithmetic progression, so the order statistic
 // is  min over i of max(A_sorted[i-1], B_ascending[n+1-i])  -- the classic two-sorted-arrays split.
 // DATA_L1 = true: the data step is TV-L1's thresholding (nltvl1_PD, :1246-1272) on rho_c.
-template <bool DATA_L1>
+// RANKED: the selection by the warp's rank table (csad_select_by_ranks); false: the sorting network (FALDOI_CSAD_SORT=1, a device-side
+// cross-check of the former).
+template <bool DATA_L1, bool RANKED = true>
 __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base, size_t pe, int nx, int ny,
                                                         float l_t, float theta, float tau)
 {
@@ -236,8 +411,10 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
         const float ixw = base[N_I1WX * pe + i], iyw = base[N_I1WY * pe + i];
         const float sg = __builtin_sqrtf(grad);
         const float r = (ixw * u1k + iyw * u2k) / sg;
-        const float m = csad_select(base + N_I0 * pe, base + N_I1W * pe, i, x, y, nx, ny, base[N_T1 * pe + i], base[N_T2 * pe + i],
-                                    r, sg, l_t);
+        const float m = RANKED ? csad_select_by_ranks(base + N_I0 * pe, base + N_I1W * pe, reinterpret_cast<const unsigned *>(base + N_RK * pe),
+                                                      pe, i, x, y, nx, ny, base[N_T1 * pe + i], base[N_T2 * pe + i], r, sg, l_t)
+                               : csad_select(base + N_I0 * pe, base + N_I1W * pe, i, x, y, nx, ny, base[N_T1 * pe + i], base[N_T2 * pe + i],
+                                             r, sg, l_t);
         v1 = u1k - ixw * m / sg;                                         // :1756-1757
         v2 = u2k - iyw * m / sg;
     }
@@ -297,7 +474,9 @@ __global__ __launch_bounds__(256) void nl_primal_kernel(float *__restrict__ base
 // ---------------------------------------------------------------------------------------------
 enum TcPlane {
     C_I0 = 0, C_I1, C_I1X, C_I1Y, C_I1W, C_I1WX, C_I1WY, C_GRAD, C_T1, C_T2, C_U1, C_U2, C_UB1, C_UB2,
-    C_X11, C_X12, C_X21, C_X22, C_ERR, C_COUNT
+    C_X11, C_X12, C_X21, C_X22, C_ERR,
+    C_RK,                                  // 12 planes: the CSAD terms' order of this warp (csad_rank_kernel)
+    C_COUNT = C_RK + 12
 };
 
 // Per warp (:1509-1538): warps, the two products inside b, ubar = u.  C_GRAD receives Ix^2 + Iy^2; the host
@@ -368,6 +547,7 @@ __global__ __launch_bounds__(256) void tc_dual_kernel(float *__restrict__ base, 
 // The squared update of every pixel goes to C_ERR (the reference's stop test sums them in pixel order) and
 // a per-block double sum to part[] (order-independent to ~1e-13: enough to decide the test whenever the mean
 // is not within the rounding slack of a serial fp32 sum around tol^2; the host settles the rest exactly).
+template <bool RANKED>
 __global__ __launch_bounds__(256) void tc_primal_kernel(float *__restrict__ base, size_t pe, int nx, int ny, float l_t,
                                                         float theta, float tau, double *__restrict__ part,
                                                         const TcCtl *__restrict__ ctl)
@@ -382,8 +562,10 @@ __global__ __launch_bounds__(256) void tc_primal_kernel(float *__restrict__ base
         const float sg = base[C_GRAD * pe + i];
         const float ixw = base[C_I1WX * pe + i], iyw = base[C_I1WY * pe + i];
         const float r = (ixw * u1k + iyw * u2k) / sg;
-        const float m = csad_select(base + C_I0 * pe, base + C_I1W * pe, i, x, y, nx, ny, base[C_T1 * pe + i], base[C_T2 * pe + i],
-                                    r, sg, l_t);
+        const float m = RANKED ? csad_select_by_ranks(base + C_I0 * pe, base + C_I1W * pe, reinterpret_cast<const unsigned *>(base + C_RK * pe),
+                                                      pe, i, x, y, nx, ny, base[C_T1 * pe + i], base[C_T2 * pe + i], r, sg, l_t)
+                               : csad_select(base + C_I0 * pe, base + C_I1W * pe, i, x, y, nx, ny, base[C_T1 * pe + i], base[C_T2 * pe + i],
+                                             r, sg, l_t);
         const float v1 = u1k - ixw * m / sg;                             // :1568-1569
         const float v2 = u2k - iyw * m / sg;
         const PixClass pc = classify(x, y, nx, ny);

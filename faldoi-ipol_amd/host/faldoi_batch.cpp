@@ -18,7 +18,12 @@
 //     `I0.png I1.png s0.flo s1.flo out.flo`      local step from the sparse seed flows, then the global step
 //   -gpus N: the program starts its N ranks itself (fork before any GPU call; the RCCL unique id travels through
 //   pipes).  Under an external launcher (RANK, LOCAL_RANK, WORLD_SIZE set, e.g. `torchrun --no-python`) the id
-//   travels through the file named by FALDOI_BATCH_ID_FILE (default /tmp/faldoi_batch_<MASTER_PORT>.id).
+//   travels through a file that is unique per run: /tmp/faldoi_batch_<launcher pid>_<MASTER_PORT>_<restart count>.id
+//   (or FALDOI_BATCH_ID_FILE); rank 0 removes whatever is there before it publishes and unlinks the file however it
+//   leaves, the others only accept a file whose writer is alive (and, for the default name, their own sibling).
+//   Nothing waits for ever: every phase that can block on another rank (rendezvous, communicator set-up, each
+//   collective) runs under a watchdog -- FALDOI_BATCH_TIMEOUT_S, default 1800 s -- that names the phase and ends the
+//   process with exit code 4; a self-started parent then ends its remaining ranks.
 //
 // Built twice from this source: against RCCL + HIP + libfaldoi_hip (the product), and with -DFALDOI_BATCH_STUB
 // (CPU test of the rank logic: pipes instead of RCCL, `flow + 1` instead of the solver, no GPU library at all).
@@ -35,7 +40,14 @@
 #include <thread>
 #include <vector>
 
+#include <atomic>
+#include <condition_variable>
+#include <csignal>
+#include <mutex>
+
+#include <sys/prctl.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -90,6 +102,129 @@ std::vector<int> shard_of(int njobs, int world, int rank)
 struct Header {                        // what rank 0 broadcasts before any payload: the job table, or why there is none
     int32_t status;                    // 0 ok, 1 = rank 0 could not read the inputs (every rank leaves with exit code 3)
     int32_t njobs, w, h, planes;       // planes: 2 = initial flow (global-only), 4 = forward + backward seed flows (pipeline)
+};
+
+// ------------------------------------------------------------------------------------------ bounded waits
+// A rank that waits for another one (rendezvous file, ncclCommInitRank, a collective) cannot know whether the peer is slow or
+// gone: RCCL's calls have no timeout of their own.  Every such phase is bracketed by a Watch; when a phase outlives the limit
+// the watchdog thread says which one and ends the PROCESS (a thread parked inside RCCL cannot be unwound) with exit code 4.
+class Watchdog {
+public:
+    static Watchdog &get() { static Watchdog *w = new Watchdog; return *w; }   // never destroyed: its thread waits on it until the process ends
+    static double limit_s()
+    {
+        const char *v = getenv("FALDOI_BATCH_TIMEOUT_S");
+        const double t = v ? atof(v) : 0.0;
+        return t > 0.0 ? t : 1800.0;
+    }
+    void arm(const char *phase, int rank)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        phase_ = phase; rank_ = rank; armed_ = true;
+        deadline_ = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(limit_s()));
+        if (!started_) { started_ = true; std::thread([this] { run(); }).detach(); }
+        cv_.notify_all();
+    }
+    void disarm() { std::lock_guard<std::mutex> g(m_); armed_ = false; cv_.notify_all(); }
+    void set_children(const std::vector<pid_t> &kids) { std::lock_guard<std::mutex> g(m_); kids_ = kids; }
+private:
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            if (!armed_) { cv_.wait(lk); continue; }
+            if (cv_.wait_until(lk, deadline_) == std::cv_status::timeout && armed_ && std::chrono::steady_clock::now() >= deadline_) {
+                fprintf(stderr, "faldoi_batch: rank %d: no progress in \"%s\" for %.0f s (FALDOI_BATCH_TIMEOUT_S): a peer is gone or hung; giving up\n",
+                        rank_, phase_, limit_s());
+                fflush(stderr);
+                for (pid_t k : kids_) (void)kill(k, SIGKILL);          // a self-started rank 0 takes its ranks with it
+                _exit(4);
+            }
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::chrono::steady_clock::time_point deadline_;
+    const char *phase_ = "";
+    int rank_ = 0;
+    bool armed_ = false, started_ = false;
+    std::vector<pid_t> kids_;
+};
+struct Watch {
+    Watch(const char *phase, int rank) { Watchdog::get().arm(phase, rank); }
+    ~Watch() { Watchdog::get().disarm(); }
+};
+
+// ------------------------------------------------------------------------------------------ rendezvous through a file (launcher mode)
+// The payload (RCCL's unique id) travels from rank 0 to the others through a file.  What can go wrong with a fixed name: an earlier
+// run on the same port that died leaves its file behind, and a rank of the NEXT run reads that stale id before rank 0 has replaced it
+// -- ncclCommInitRank then never completes.  So: the default name carries the launcher's pid (every rank's parent) and the restart
+// count; rank 0 removes what is there before anything else, writes {magic, its pid, payload} to a temporary name and renames it, and
+// unlinks it however it leaves (RendezvousFile's destructor); a reader accepts a file only if its writer is alive and -- for the
+// default name -- a child of the reader's own parent.
+struct RendezvousRecord {
+    uint64_t magic;
+    int64_t writer_pid;
+    unsigned char payload[256];
+};
+constexpr uint64_t kRendezvousMagic = 0x46414c444f494231ull;           // "FALDOIB1"
+
+[[maybe_unused]] std::string rendezvous_default_name()
+{
+    const char *port = getenv("MASTER_PORT"), *restart = getenv("TORCHELASTIC_RESTART_COUNT");
+    return std::string("/tmp/faldoi_batch_") + std::to_string((long)getppid()) + "_" + (port ? port : "0") + "_" + (restart ? restart : "0") + ".id";
+}
+long parent_of(long pid)                                               // field 4 of /proc/<pid>/stat; -1: no such process
+{
+    std::ifstream f("/proc/" + std::to_string(pid) + "/stat");
+    std::string line;
+    if (!f || !std::getline(f, line)) return -1;
+    const size_t close = line.rfind(')');                              // the command name may hold spaces and parentheses
+    if (close == std::string::npos) return -1;
+    std::istringstream ss(line.substr(close + 1));
+    std::string state;
+    long ppid = -1;
+    ss >> state >> ppid;
+    return ppid;
+}
+struct RendezvousFile {
+    std::string path;
+    bool owner = false;
+    ~RendezvousFile() { if (owner) (void)unlink(path.c_str()); }
+    void publish(const void *payload, size_t bytes)
+    {
+        if (bytes > sizeof(RendezvousRecord::payload)) throw std::runtime_error("rendezvous payload too large");
+        (void)unlink(path.c_str());                                     // a leftover of an earlier run must not be read as ours
+        owner = true;
+        RendezvousRecord rec{};
+        rec.magic = kRendezvousMagic;
+        rec.writer_pid = (int64_t)getpid();
+        memcpy(rec.payload, payload, bytes);
+        const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&rec, sizeof rec, 1, f) != 1) { if (f) fclose(f); (void)unlink(tmp.c_str()); throw std::runtime_error("cannot write " + tmp); }
+        fclose(f);
+        if (rename(tmp.c_str(), path.c_str())) { (void)unlink(tmp.c_str()); throw std::runtime_error("cannot publish " + path); }
+    }
+    // Polls until a record of a live writer is there (same_parent: the writer must be a child of this process's parent); bounded by
+    // the watchdog's limit.
+    void fetch(void *payload, size_t bytes, bool same_parent) const
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            RendezvousRecord rec{};
+            FILE *f = fopen(path.c_str(), "rb");
+            const bool got = f && fread(&rec, sizeof rec, 1, f) == 1;
+            if (f) fclose(f);
+            if (got && rec.magic == kRendezvousMagic) {
+                const long pp = parent_of((long)rec.writer_pid);
+                if (pp >= 0 && (!same_parent || pp == (long)getppid())) { memcpy(payload, rec.payload, bytes); return; }
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > Watchdog::limit_s())
+                throw std::runtime_error("no rendezvous record of a live rank 0 in " + path);
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        }
+    }
 };
 
 // ------------------------------------------------------------------------------------------ communicators
@@ -328,7 +463,7 @@ int run_rank(Comm &comm, int device, const Options &o, const std::string &jobs_f
             hd.status = 1;
         }
     }
-    comm.bcast(&hd, sizeof hd);
+    { Watch w("broadcast of the job table (rank 0 reads the inputs first)", comm.rank); comm.bcast(&hd, sizeof hd); }
     if (hd.status) return 3;
     const int njobs = hd.njobs, w = hd.w, h = hd.h, planes = hd.planes, world = comm.world;
     const size_t px = (size_t)w * h;
@@ -348,8 +483,15 @@ int run_rank(Comm &comm, int device, const Options &o, const std::string &jobs_f
             }
         }
     }
-    comm.scatter(fr_all.data(), fr_mine.data(), fr_chunk);
-    comm.scatter(fl_all.data(), fl_mine.data(), fl_chunk);
+    {
+        Watch w("distribution of the shards", comm.rank);
+        comm.scatter(fr_all.data(), fr_mine.data(), fr_chunk);
+        comm.scatter(fl_all.data(), fl_mine.data(), fl_chunk);
+    }
+    if (const char *v = getenv("FALDOI_BATCH_TEST_HANG_RANK"))           // test hook: this rank stops taking part (a hung peer)
+        if (atoi(v) == comm.rank) for (;;) pause();
+    if (const char *v = getenv("FALDOI_BATCH_TEST_DIE_RANK"))            // test hook: this rank dies between two collectives
+        if (atoi(v) == comm.rank) _exit(9);
     std::vector<float> out_mine((size_t)cap * 2 * px, 0.0f), out_all;
     int status = 0;
     try {
@@ -359,10 +501,13 @@ int run_rank(Comm &comm, int device, const Options &o, const std::string &jobs_f
         status = 3;                                                     // still takes part in the gather: nobody is left waiting
     }
     if (comm.rank == 0) out_all.resize((size_t)cap * 2 * px * world);
-    comm.gather(out_mine.data(), out_all.data(), sizeof(float) * cap * 2 * px);
     std::vector<int32_t> st_all(world, 0);
     const int32_t st_mine = status;
-    comm.gather(&st_mine, st_all.data(), sizeof(int32_t));
+    {
+        Watch w("collection of the flows (waits for the slowest rank's solve)", comm.rank);
+        comm.gather(out_mine.data(), out_all.data(), sizeof(float) * cap * 2 * px);
+        comm.gather(&st_mine, st_all.data(), sizeof(int32_t));
+    }
     if (comm.rank == 0) {
         for (int r = 0; r < world; ++r) if (st_all[r]) status = st_all[r];
         if (!status) {
@@ -375,9 +520,37 @@ int run_rank(Comm &comm, int device, const Options &o, const std::string &jobs_f
         }
     }
     int32_t fin = status;
-    comm.bcast(&fin, sizeof fin);                                       // every rank leaves with rank 0's verdict
-    comm.barrier();
+    {
+        Watch w("final verdict", comm.rank);
+        comm.bcast(&fin, sizeof fin);                                   // every rank leaves with rank 0's verdict
+        comm.barrier();
+    }
     return fin;
+}
+
+// Rank 0 of a self-started run collects its ranks.  When it leaves with an error itself, or a rank does, the ranks that are still
+// running are waiting for somebody who will not come: they are given a moment to notice (their own watchdogs and pipe errors), then ended.
+int reap(const std::vector<pid_t> &kids, int rc)
+{
+    std::vector<pid_t> left(kids);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!left.empty()) {
+        for (size_t k = 0; k < left.size();) {
+            int st = 0;
+            const pid_t r = waitpid(left[k], &st, WNOHANG);
+            if (r == 0) { ++k; continue; }
+            if (r < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != rc) rc = rc ? rc : ((r > 0 && WIFEXITED(st) && WEXITSTATUS(st)) ? WEXITSTATUS(st) : 3);
+            left.erase(left.begin() + (long)k);
+        }
+        if (left.empty()) break;
+        if (rc && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+            for (pid_t k : left) (void)kill(k, SIGKILL);
+            for (pid_t k : left) { int st = 0; (void)waitpid(k, &st, 0); }
+            break;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+    return rc;
 }
 
 }  // namespace
@@ -385,6 +558,29 @@ int run_rank(Comm &comm, int device, const Options &o, const std::string &jobs_f
 int main(int argc, char *argv[])
 {
     std::vector<std::string> args(argv, argv + argc);
+    // faldoi_batch --rendezvous-selftest FILE publish|fetch|fetch-sibling TOKEN: the launcher-mode rendezvous alone (CPU tests)
+    if (argc == 5 && std::string(argv[1]) == "--rendezvous-selftest") {
+        try {
+            RendezvousFile rv;
+            rv.path = argv[2];
+            char tok[64] = {0};
+            const std::string mode = argv[3];
+            if (mode == "publish") {
+                strncpy(tok, argv[4], sizeof tok - 1);
+                rv.publish(tok, sizeof tok);
+                printf("published\n");
+                fflush(stdout);
+                (void)getchar();                                        // holds the record (and stays alive) until stdin closes
+                return 0;
+            }
+            rv.fetch(tok, sizeof tok, mode == "fetch-sibling");
+            printf("%s\n", tok);
+            return 0;
+        } catch (const std::exception &e) {
+            fprintf(stderr, "faldoi_batch: %s\n", e.what());
+            return 3;
+        }
+    }
     Options o;
     int gpus = 1;
     try {
@@ -413,33 +609,27 @@ int main(int argc, char *argv[])
             fprintf(stderr, "faldoi_batch (stub build): start it with -gpus N\n");
             return 1;
 #else
-            // ---- under an external launcher: the unique id travels through a file
+            // ---- under an external launcher: the unique id travels through a file that is unique per run (RendezvousFile)
             RcclComm comm;
             comm.world = atoi(env_world);
             comm.rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
             const int device = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : comm.rank;
-            std::string idf = getenv("FALDOI_BATCH_ID_FILE") ? getenv("FALDOI_BATCH_ID_FILE")
-                                                             : std::string("/tmp/faldoi_batch_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
+            const bool named = getenv("FALDOI_BATCH_ID_FILE") != nullptr;
+            RendezvousFile rv;
+            rv.path = named ? getenv("FALDOI_BATCH_ID_FILE") : rendezvous_default_name();
             ncclUniqueId id;
-            if (comm.rank == 0) {
-                NCCL_OK(ncclGetUniqueId(&id));
-                const std::string tmp = idf + ".tmp";
-                FILE *f = fopen(tmp.c_str(), "wb");
-                if (!f || fwrite(&id, sizeof id, 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
-                fclose(f);
-                if (rename(tmp.c_str(), idf.c_str())) throw std::runtime_error("cannot publish " + idf);
-            } else {
-                for (int tries = 0;; ++tries) {
-                    FILE *f = fopen(idf.c_str(), "rb");
-                    if (f) { const bool ok = fread(&id, sizeof id, 1, f) == 1; fclose(f); if (ok) break; }
-                    if (tries > 600) throw std::runtime_error("no RCCL id in " + idf + " after 60 s");
-                    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            {
+                Watch w("rendezvous and communicator set-up", comm.rank);
+                if (comm.rank == 0) {
+                    (void)unlink(rv.path.c_str());                      // before anything else: no rank may pick up an earlier run's id
+                    NCCL_OK(ncclGetUniqueId(&id));
+                    rv.publish(&id, sizeof id);
+                } else {
+                    rv.fetch(&id, sizeof id, !named);
                 }
+                comm.init(device, id);
             }
-            comm.init(device, id);
-            const int rc = run_rank(comm, device, o, jobs_file);
-            if (comm.rank == 0) (void)unlink(idf.c_str());
-            return rc;
+            return run_rank(comm, device, o, jobs_file);                // (rv's destructor unlinks the file on every way out)
 #endif
         }
         // ---- self-started ranks: fork BEFORE anything touches a GPU; rank 0 hands the unique id (RCCL) or nothing (stub) down pipes
@@ -455,9 +645,16 @@ int main(int argc, char *argv[])
         for (int r = 1; r < gpus; ++r) {
             const pid_t pid = fork();
             if (pid < 0) throw std::runtime_error("fork failed");
-            if (pid == 0) { my_rank = r; kids.clear(); break; }
+            if (pid == 0) {
+                my_rank = r;
+                kids.clear();
+                (void)prctl(PR_SET_PDEATHSIG, SIGKILL);                 // a rank never outlives rank 0, however that one ends
+                if (getppid() == 1) _exit(3);
+                break;
+            }
             kids.push_back(pid);
         }
+        if (my_rank == 0) Watchdog::get().set_children(kids);
         for (int r = 1; r < gpus; ++r) {                                // keep only this rank's ends
             if (my_rank == 0) close(down[r]);
             else { close(up[r]); if (r != my_rank) close(down[r]); }
@@ -470,28 +667,37 @@ int main(int argc, char *argv[])
         comm.fd.assign(gpus, -1);
         if (my_rank == 0) for (int r = 1; r < gpus; ++r) comm.fd[r] = up[r];
         else comm.fd[0] = down[my_rank];
-        rc = run_rank(comm, my_rank, o, jobs_file);
-#else
-        ncclUniqueId id;
-        if (my_rank == 0) {
-            NCCL_OK(ncclGetUniqueId(&id));
-            for (int r = 1; r < gpus; ++r)
-                if (write(up[r], &id, sizeof id) != (ssize_t)sizeof id) throw std::runtime_error("cannot hand the RCCL id to a rank");
-        } else if (read(down[my_rank], &id, sizeof id) != (ssize_t)sizeof id) {
-            throw std::runtime_error("no RCCL id from rank 0");
+        try {
+            rc = run_rank(comm, my_rank, o, jobs_file);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "faldoi_batch: rank %d: %s\n", my_rank, e.what());
+            rc = 3;
         }
-        RcclComm comm;
-        comm.rank = my_rank;
-        comm.world = gpus;
-        comm.init(my_rank, id);
-        rc = run_rank(comm, my_rank, o, jobs_file);
+#else
+        try {
+            ncclUniqueId id;
+            RcclComm comm;
+            comm.rank = my_rank;
+            comm.world = gpus;
+            {
+                Watch w("hand-over of the RCCL id and communicator set-up", my_rank);
+                if (my_rank == 0) {
+                    NCCL_OK(ncclGetUniqueId(&id));
+                    for (int r = 1; r < gpus; ++r)
+                        if (write(up[r], &id, sizeof id) != (ssize_t)sizeof id) throw std::runtime_error("cannot hand the RCCL id to a rank");
+                } else if (read(down[my_rank], &id, sizeof id) != (ssize_t)sizeof id) {
+                    throw std::runtime_error("no RCCL id from rank 0");
+                }
+                comm.init(my_rank, id);
+            }
+            rc = run_rank(comm, my_rank, o, jobs_file);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "faldoi_batch: rank %d: %s\n", my_rank, e.what());
+            rc = 3;
+        }
 #endif
         if (my_rank != 0) _exit(rc);
-        for (pid_t k : kids) {
-            int st = 0;
-            if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != rc) rc = rc ? rc : 3;
-        }
-        return rc;
+        return reap(kids, rc);
     } catch (const std::exception &e) {
         fprintf(stderr, "faldoi_batch: %s\n", e.what());
         return 3;

@@ -1,0 +1,104 @@
+"""GPU suite, round 4: the CSAD selection by the warp's rank table (six probes instead of a 48-input sort per pixel and
+iteration) against the sorting-network form it replaces and against the CPU checker, which sorts like the reference
+(src/global_faldoi.cpp:1733-1758, :1547-1571).  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+
+import faldoi_ipol_amd as F
+from util import bits_equal, mismatch_report, sintel_pair
+
+pytestmark = pytest.mark.gpu
+W, H = 1024, 436
+
+
+def _crop_inputs(oracle, rng, w, h):
+    full0, full1 = sintel_pair()
+    x0, y0 = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+    c0 = np.ascontiguousarray(full0[:, y0:y0 + h, x0:x0 + w])
+    c1 = np.ascontiguousarray(full1[:, y0:y0 + h, x0:x0 + w])
+    lab = F.capi.image_to_lab(c0)
+    if min(w, h) >= 6:
+        i0n, i1n = oracle.preprocess_global(c0, c1)
+    else:                                        # smaller than the Gaussian's support: gray planes as they are
+        i0n, i1n = c0.mean(axis=0) / np.float32(255), c1.mean(axis=0) / np.float32(255)
+    return i0n, i1n, lab
+
+
+def _degenerate(rng, kind, w, h):
+    """Frames that make the CSAD terms tie: flat regions (every term of a pixel equal, b == r happens: -0 among the sorted
+    values), two grey levels, a ramp (equal terms along rows), and frames with exact zeros."""
+    if kind == 0:
+        a = np.zeros((h, w), np.float32)
+        a[:, w // 2:] = 1.0
+        b = np.roll(a, 1, axis=1)
+    elif kind == 1:
+        a = np.tile(np.arange(w, dtype=np.float32) / np.float32(w), (h, 1))
+        b = np.roll(a, 2, axis=1)
+    elif kind == 2:
+        a = (rng.integers(0, 2, (h, w))).astype(np.float32)
+        b = np.roll(a, 1, axis=0)
+    else:
+        a = (rng.integers(0, 3, (h, w)) * 0.5).astype(np.float32)
+        b = (rng.integers(0, 3, (h, w)) * 0.5).astype(np.float32)
+    lab = np.stack([a * 100, a * 0, a * 0]).astype(np.float32)
+    return np.ascontiguousarray(a), np.ascontiguousarray(b), lab
+
+
+def test_csad_selection_by_ranks_equals_the_sorting_network_and_the_checker(ctx, oracle, monkeypatch):
+    """NLTV-CSAD on the fused kernel and on the two streaming kernels, TV-CSAD: the rank-table selection (product path) returns
+    the bits of the per-iteration sorting network (FALDOI_CSAD_SORT=1, the round-3 form) -- including the sign of a zero --
+    on crops of the example pair (every tile height, ragged tiles, images smaller than the 7x7 window, several warps: the
+    table is rebuilt per warp) and on frames built to make the 48 terms tie; small cases also equal the CPU checker."""
+    rng = np.random.default_rng(40401)
+    checked = 0
+    for case in range(36):
+        if case < 6:
+            w, h = [(2, 2), (3, 7), (64, 16), (65, 17), (130, 35), (7, 40)][case]
+        elif case < 14:
+            w, h = int(rng.integers(8, 90)), int(rng.integers(8, 60))
+        else:
+            w, h = int(rng.integers(6, 420)), int(rng.integers(6, 150))
+        if 6 <= case < 14:
+            i0n, i1n, lab = _degenerate(rng, case % 4, w, h)
+        else:
+            i0n, i1n, lab = _crop_inputs(oracle, rng, w, h)
+        sd = float(rng.choice([0, 0.5, 3.0]))
+        u0 = rng.normal(0, sd, (2, h, w)).astype(np.float32)
+        if case % 5 == 0:
+            u0 = np.round(u0)                    # integer flows: exact zeros among the terms
+        prm = dict(warps=int(rng.integers(1, 4)), max_inner=int(rng.integers(1, 14)))
+        tv = case % 3 == 2
+        if tv:
+            def solve():
+                return ctx.tvcsad_global(i0n, i1n, u0, warps=prm["warps"], max_inner=prm["max_inner"])[0]
+        else:
+            def solve():
+                return ctx.nltvcsad_global(i0n, i1n, lab, u0, **prm)[0]
+        monkeypatch.setenv("FALDOI_CSAD_SORT", "1")
+        ref = solve()
+        monkeypatch.delenv("FALDOI_CSAD_SORT")
+        outs = []
+        if tv:
+            outs.append(("tvcsad", solve()))
+        else:
+            monkeypatch.setenv("FALDOI_NL_FUSED", "0")
+            outs.append(("two kernels", solve()))
+            monkeypatch.setenv("FALDOI_NL_FUSED", "1")
+            rows = [None, 8, 12, 14, 16][case % 5]
+            if rows:
+                monkeypatch.setenv("FALDOI_NL_ROWS", str(rows))
+            else:
+                monkeypatch.delenv("FALDOI_NL_ROWS", raising=False)
+            outs.append(("fused rows=%s" % rows, solve()))
+            monkeypatch.delenv("FALDOI_NL_FUSED")
+            monkeypatch.delenv("FALDOI_NL_ROWS", raising=False)
+        for name, got in outs:
+            assert bits_equal(got, ref), (case, name, w, h, prm, mismatch_report(got, ref))
+        if w * h <= 6000 and not tv:
+            want = oracle.nltvcsad_global(i0n, i1n, lab, u0, **prm)
+            want = want[0] if isinstance(want, tuple) else want
+            # (the checker's std::sort may order a tied -0 / +0 pair either way: compare values, and bits away from zeros)
+            got = outs[-1][1]
+            assert np.array_equal(got, want), (case, w, h, mismatch_report(got, want))
+            checked += 1
+    assert checked >= 8

@@ -267,3 +267,84 @@ def test_batch_host_without_a_gpu_ends_every_rank(bins, tmp_path):
         r = subprocess.run([bins["faldoi_batch"], str(jobs), "-gpus", gpus], capture_output=True, text=True, timeout=120)
         assert r.returncode == 3, (gpus, r.returncode, r.stderr[-500:])
         assert "faldoi_batch:" in r.stderr
+
+
+@pytest.mark.parametrize("njobs", [32, 29])
+def test_batch_host_eight_ranks_32_jobs(bins, tmp_path, njobs):
+    """BASELINE configs[3]'s shape on the rank logic alone: 8 ranks, 32 jobs (four per rank, exact) and 29 (ragged last round:
+    ranks 5..7 hold three), stub communicator; every output lands in its own file with its own job's content."""
+    rng = np.random.default_rng(800 + njobs)
+    jobs, want = _batch_inputs(tmp_path, njobs, False, rng)
+    r = subprocess.run([bins["faldoi_batch_stub"], str(jobs), "-gpus", "8"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "%d pairs on 8 GPU(s) written" % njobs in r.stdout
+    for path, flow in want:
+        got = F.flo.read_flo(str(path))
+        assert np.array_equal(got.view(np.uint32), flow.view(np.uint32)), path
+
+
+def _no_stub_left():
+    out = subprocess.run(["ps", "-eo", "pid,comm"], capture_output=True, text=True).stdout
+    return not any("faldoi_batch_st" in line for line in out.splitlines())
+
+
+@pytest.mark.parametrize("hook,rank", [("FALDOI_BATCH_TEST_HANG_RANK", 1), ("FALDOI_BATCH_TEST_HANG_RANK", 2),
+                                       ("FALDOI_BATCH_TEST_DIE_RANK", 2), ("FALDOI_BATCH_TEST_DIE_RANK", 0)])
+def test_batch_host_never_waits_for_ever(bins, tmp_path, hook, rank):
+    """A rank that hangs or dies between two collectives (test hooks): the ranks waiting for it give up after
+    FALDOI_BATCH_TIMEOUT_S (watchdog, exit code 4) or see their pipe close (3); rank 0 ends whatever is left; the program
+    returns non-zero within seconds and leaves no process behind."""
+    import time
+    rng = np.random.default_rng(77)
+    jobs, _ = _batch_inputs(tmp_path, 6, False, rng)
+    env = dict(os.environ, FALDOI_BATCH_TIMEOUT_S="2")
+    env[hook] = str(rank)
+    t0 = time.time()
+    r = subprocess.run([bins["faldoi_batch_stub"], str(jobs), "-gpus", "3"], capture_output=True, text=True, timeout=60, env=env)
+    took = time.time() - t0
+    assert r.returncode != 0, (hook, rank, r.stdout, r.stderr)
+    assert took < 20, took
+    if hook.endswith("HANG_RANK"):
+        assert "no progress in" in r.stderr and "FALDOI_BATCH_TIMEOUT_S" in r.stderr, r.stderr
+    for _ in range(50):
+        if _no_stub_left():
+            break
+        time.sleep(0.1)
+    assert _no_stub_left()
+
+
+def test_batch_host_rendezvous_file_ignores_a_stale_record(bins, tmp_path):
+    """The launcher-mode rendezvous (the RCCL id travels through a file): a record left behind by a rank 0 that no longer
+    exists is not accepted -- the reader keeps polling until a live rank 0 has published --, a record whose writer is not the
+    reader's sibling is not accepted under the default (per-launcher) name, rank 0 replaces what it finds and removes its
+    file when it leaves, and a reader without any rank 0 gives up after FALDOI_BATCH_TIMEOUT_S."""
+    import struct
+    import time
+    exe = bins["faldoi_batch_stub"]
+    path = tmp_path / "rv.id"
+    dead = subprocess.Popen(["true"])
+    dead.wait()
+    stale = struct.pack("<Qq", 0x46414c444f494231, dead.pid) + b"stale".ljust(256, b"\0")
+    path.write_bytes(stale)
+    env = dict(os.environ, FALDOI_BATCH_TIMEOUT_S="20")
+    reader = subprocess.Popen([exe, "--rendezvous-selftest", str(path), "fetch", "-"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    time.sleep(0.5)
+    assert reader.poll() is None                                   # still polling: the stale record was not taken
+    writer = subprocess.Popen([exe, "--rendezvous-selftest", str(path), "publish", "fresh-token"], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, text=True, env=env)
+    assert writer.stdout.readline().strip() == "published"
+    out, err = reader.communicate(timeout=30)
+    assert reader.returncode == 0 and out.strip() == "fresh-token", (out, err)
+    # a sibling check: this test process is the parent of both, so a sibling fetch succeeds ...
+    r = subprocess.run([exe, "--rendezvous-selftest", str(path), "fetch-sibling", "-"], capture_output=True, text=True, timeout=30, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "fresh-token"
+    # ... and one started by another parent (a shell in between) does not accept the record
+    r = subprocess.run(["sh", "-c", "%s --rendezvous-selftest %s fetch-sibling - ; exit $?" % (exe, path)], capture_output=True, text=True,
+                       timeout=30, env=dict(env, FALDOI_BATCH_TIMEOUT_S="1"))
+    assert r.returncode == 3 and "no rendezvous record of a live rank 0" in r.stderr
+    writer.stdin.close()
+    assert writer.wait(timeout=30) == 0
+    assert not path.exists()                                       # rank 0 unlinks its record however it leaves
+    r = subprocess.run([exe, "--rendezvous-selftest", str(path), "fetch", "-"], capture_output=True, text=True, timeout=30,
+                       env=dict(env, FALDOI_BATCH_TIMEOUT_S="1"))
+    assert r.returncode == 3
