@@ -52,6 +52,27 @@ def hipcc():
     raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU fallback)")
 
 
+SO_CHECK = os.path.join(HERE, "libfaldoi_hip_check.so")       # the same sources with -DFALDOI_NL_CHECK=1 (nltv_fused_kernel.hpp: nf_check)
+
+
+def build_check(force=False):
+    """The range-checked build of the library: every LDS index and slab offset of the fused NLTV kernel is compared with its extent
+    (tests/test_gpu_round4.py runs the geometry sweep on it once, in a child process).  Not a product artefact; same lock, same
+    freshness rule as the product library."""
+    fresh = os.path.exists(SO_CHECK) and all(os.path.getmtime(d) <= os.path.getmtime(SO_CHECK) for d in DEPS)
+    if fresh and not force:
+        return SO_CHECK
+    with _build_lock():
+        tmp = SO_CHECK + ".tmp.%d" % os.getpid()
+        cmd = [hipcc()] + HIPCC_FLAGS + ["-DFALDOI_NL_CHECK=1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+                                         "-o", tmp] + SOURCES
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on the range-checked build:\n" + r.stderr[-4000:])
+        os.replace(tmp, SO_CHECK)
+    return SO_CHECK
+
+
 def needs_build():
     if not os.path.exists(SO):
         return True

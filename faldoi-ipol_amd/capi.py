@@ -76,8 +76,17 @@ class FaldoiError(RuntimeError):
 _lib = None
 
 
+_lib_path = None
+
+
 def library_path():
-    return _build.SO
+    """The library this process loaded (the product's unless FALDOI_LIB named another one); before the first call of lib(): the product's."""
+    return _lib_path or _build.SO
+
+
+def loaded_library():
+    """Absolute path of the library this process runs on (None before the first call of lib()) and whether it is the product's."""
+    return _lib_path, (_lib_path is not None and os.path.abspath(_build.SO) == _lib_path)
 
 
 def lib():
@@ -86,13 +95,20 @@ def lib():
     if _lib is not None:
         return _lib
     so = _build.SO
-    if os.environ.get("FALDOI_LIB"):                  # development aid: a timing-only build of the library (tools/nl_whatif.sh)
+    if os.environ.get("FALDOI_LIB"):
+        # Development aid ONLY (timing-only builds of tools/nl_whatif.sh, the range-checked build of build.build_check): the library named
+        # here is loaded as it is -- no freshness check, and a what-if build returns wrong results by construction.  Said loudly, and
+        # recorded: loaded_library() is what bench.py prints and what makes it refuse every counter-derived field.
         so = os.environ["FALDOI_LIB"]
+        import sys
+        sys.stderr.write("faldoi_ipol_amd: FALDOI_LIB is set -- loading %s INSTEAD of the product library %s\n" % (so, _build.SO))
     elif _build.needs_build():
         so = _build.build()
     if not os.path.exists(so):
         raise RuntimeError("libfaldoi_hip.so is missing and could not be built; the HIP path has no fallback")
     L = C.CDLL(so)
+    global _lib_path
+    _lib_path = os.path.abspath(so)
     vp = C.c_void_p
     L.faldoi_abi_version.restype = C.c_int
     L.faldoi_last_error.restype = C.c_char_p
@@ -104,6 +120,7 @@ def lib():
     L.faldoi_ctx_persist_stats.argtypes = [vp] + [C.POINTER(C.c_long)] * 4
     L.faldoi_ctx_persist_retry.argtypes = [vp]
     L.faldoi_ctx_exact_redos.argtypes = [vp, C.POINTER(C.c_long)]
+    L.faldoi_debug_nl_check.argtypes = [vp, C.POINTER(C.c_uint * 4), C.c_int, C.POINTER(C.c_int)]
     L.faldoi_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
     L.faldoi_tvl1_default_params.restype = None
     L.faldoi_tvl1_global.argtypes = [vp, _F, _F, _F, vp, C.c_int, C.c_int, C.POINTER(Tvl1Params),
@@ -384,6 +401,13 @@ class Context:
         """Mirror of nltvcsad_PD.  Returns (u, device ms)."""
         return self._nl_global(lib().faldoi_nltvcsad_default_params, lib().faldoi_nltvcsad_global,
                                i0n, i1n, lab, u0, params)
+
+    def nl_check_report(self, reset=True):
+        """faldoi_debug_nl_check: (bits, violations, largest offending value, launches checked, compiled_in)."""
+        out = (C.c_uint * 4)()
+        comp = C.c_int(0)
+        _check(lib().faldoi_debug_nl_check(self._h, C.byref(out), 1 if reset else 0, C.byref(comp)))
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3]), bool(comp.value)
 
     def nltvl1_global(self, i0n, i1n, lab, u0, **params):
         """Mirror of nltvl1_PD.  Returns (u, device ms)."""

@@ -1449,6 +1449,22 @@ static hipError_t nl_fused_prepare(bool data_l1, int ty) { FALDOI_NL_DISPATCH(nl
 static hipError_t nl_fused_launch(bool data_l1, int ty, hipStream_t s, const NfArgs &a) { FALDOI_NL_DISPATCH(nl_fused_launch_t, s, a); }
 #undef FALDOI_NL_DISPATCH
 
+extern "C" int faldoi_debug_nl_check(faldoi_ctx *ctx, unsigned out[4], int reset, int *compiled_in)
+{
+    return abi_guard("the NLTV range-check report", [&] {
+        if (!ctx || !out) return fail(FALDOI_ERR_INVALID, "NULL argument");
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nf_check), 4 * sizeof(unsigned)));
+        if (reset) {
+            const unsigned zero[4] = { 0u, 0u, 0u, 0u };
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_nf_check), zero, sizeof zero));
+        }
+        if (compiled_in) *compiled_in = kNfCheck ? 1 : 0;
+        return (int)FALDOI_OK;
+    });
+}
+
 static bool csad_sort_requested()
 {
     const char *v = getenv("FALDOI_CSAD_SORT");
@@ -1511,6 +1527,7 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
         fa.base = base; fa.pe = pe; fa.nx = nx; fa.ny = ny;
         fa.ntx = (nx + kNfW - 1) / kNfW; fa.nty = (ny + ty - 1) / ty;
         fa.cur = 0; fa.tau = prm->tau; fa.l_t = l_t; fa.theta = prm->theta; fa.rtheta = 1.0 / (double)prm->theta;
+        fa.check_selftest = (getenv("FALDOI_NL_CHECK_SELFTEST") && atoi(getenv("FALDOI_NL_CHECK_SELFTEST")) > 0) ? 1 : 0;
         HIP_TRY(nl_fused_prepare(data_l1, ty));
     }
     HIP_TRY(hipEventRecord(ctx->ev0, s));

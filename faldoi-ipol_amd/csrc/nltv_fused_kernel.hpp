@@ -24,7 +24,7 @@
 #pragma clang fp contract(off)
 
 // FALDOI_NFWHATIF (timing-only builds, wrong results; tools/nl_whatif.sh): 1 no data step | 2 no crossing edges | 4 trivial dual
-// arithmetic | 16 no HBM stores of the duals
+// arithmetic | 16 no HBM stores of the duals | 64 the weights of slots 12..23 not loaded | 128 rank words 9..11 not loaded
 #ifndef FALDOI_NFWHATIF
 #define FALDOI_NFWHATIF 0
 #endif
@@ -33,6 +33,26 @@
 namespace faldoi {
 
 constexpr int kNfWhatIf = FALDOI_NFWHATIF;
+
+// FALDOI_NL_CHECK=1 (the second library build.py makes, libfaldoi_hip_check.so; tests/test_gpu_round4.py runs the geometry sweep on it
+// once): every LDS index and every slab offset this kernel forms is compared with the extent it must stay inside -- the array of the
+// LDS struct, the pixel range of a plane, the slab -- and a violation raises a bit of g_nf_check[0] (which check) and records the
+// offending value; the access itself is then made at index 0.  In the product build the checks compile to nothing.
+#ifndef FALDOI_NL_CHECK
+#define FALDOI_NL_CHECK 0
+#endif
+constexpr bool kNfCheck = FALDOI_NL_CHECK != 0;
+enum NfCheckBit { NFC_PQ = 0, NFC_UB, NFC_IM, NFC_PIXEL, NFC_SLAB, NFC_PLANE, NFC_STAGE_LDS, NFC_CROSS_AT, NFC_RANK_BYTE };
+__device__ unsigned g_nf_check[4];            // [0] bits of NfCheckBit, [1] number of violations, [2] largest offending value, [3] launches checked
+__device__ __forceinline__ bool nf_check(bool ok, int bit, unsigned value)
+{
+    if (kNfCheck && !ok) {
+        atomicOr(&g_nf_check[0], 1u << bit);
+        atomicAdd(&g_nf_check[1], 1u);
+        atomicMax(&g_nf_check[2], value);
+    }
+    return !kNfCheck || ok;
+}
 constexpr int kNfW = 64;                      // tile width: one wavefront per tile row
 constexpr int kNfLW = kNfW + 2 * kNlR;        // 68: LDS row of a dual plane / of ubar (2-pixel ring)
 constexpr int kNfIW = kNfW + 8;                // 72: LDS row of the staged I0 / I1w (3-pixel ring, 70 used): a window position byte
@@ -42,7 +62,33 @@ template <int TY> struct NfLds {
     float pq[kNlSlots][TY + 2 * kNlR][kNfLW];
     float ub[2][TY + 2 * kNlR][kNfLW];
     float im[2][TY + 2 * kCsR][kNfIW];
+    // every access goes through these (FALDOI_NL_CHECK: range-checked, see nf_check; otherwise plain indexing)
+    __device__ __forceinline__ float &pq_at(int s, int r, int c);
+    __device__ __forceinline__ float &pq_flat(int at);
+    __device__ __forceinline__ float &ub_at(int comp, int r, int c);
+    __device__ __forceinline__ float &im_at(int comp, int r, int c);
 };
+
+template <int TY> __device__ __forceinline__ float &NfLds<TY>::pq_at(int s, int r, int c)
+{
+    const bool ok = nf_check(s >= 0 && s < kNlSlots && r >= 0 && r < TY + 2 * kNlR && c >= 0 && c < kNfLW, NFC_PQ, (unsigned)((s * 64 + r) * 128 + c));
+    return ok ? pq[s][r][c] : pq[0][0][0];
+}
+template <int TY> __device__ __forceinline__ float &NfLds<TY>::pq_flat(int at)
+{
+    const bool ok = nf_check(at >= 0 && at < kNlSlots * (TY + 2 * kNlR) * kNfLW, NFC_CROSS_AT, (unsigned)at);
+    return (&pq[0][0][0])[ok ? at : 0];
+}
+template <int TY> __device__ __forceinline__ float &NfLds<TY>::ub_at(int comp, int r, int c)
+{
+    const bool ok = nf_check(comp >= 0 && comp < 2 && r >= 0 && r < TY + 2 * kNlR && c >= 0 && c < kNfLW, NFC_UB, (unsigned)((comp * 64 + r) * 128 + c));
+    return ok ? ub[comp][r][c] : ub[0][0][0];
+}
+template <int TY> __device__ __forceinline__ float &NfLds<TY>::im_at(int comp, int r, int c)
+{
+    const bool ok = nf_check(comp >= 0 && comp < 2 && r >= 0 && r < TY + 2 * kCsR && c >= 0 && c < kNfW + 2 * kCsR, NFC_IM, (unsigned)((comp * 64 + r) * 128 + c));
+    return ok ? im[comp][r][c] : im[0][0][0];
+}
 
 struct NfArgs {
     float *base;
@@ -51,19 +97,36 @@ struct NfArgs {
     int cur;                                  // which buffer of the duals / ubar holds the state this iteration reads
     float tau, l_t, theta;
     double rtheta;                            // 1 / theta in double (host), for the exact quotients by theta
+    int check_selftest;                       // check build, FALDOI_NL_CHECK_SELFTEST=1: one deliberately out-of-range index per kind (the
+                                              // detector must not be vacuous)
 };
 
 // Plane accesses go through ONE buffer resource over the whole slab: the per-lane byte offset of a pixel sits in one VGPR and the
 // plane's offset (uniform) in an SGPR, instead of a 64-bit address per access (host: the slab is below 4 GB, else the two-kernel
 // path runs).
 typedef __amdgpu_buffer_rsrc_t NfRsrc;
+// (check build: g_nf_extent = { bytes of a plane's pixels, bytes of a plane, bytes of the slab }, set by the kernel's first statement)
+__device__ unsigned g_nf_extent[3];
+__device__ __forceinline__ unsigned nf_checked_off(unsigned plane_bytes, unsigned voff)
+{
+    if (!kNfCheck) return voff;
+    bool ok = nf_check((voff & 3u) == 0u && (plane_bytes % g_nf_extent[1]) == 0u, NFC_PLANE, plane_bytes);
+    // a pixel of a plane: the plane sits in the scalar offset, or (crossing edges) is folded into the lane offset
+    ok &= nf_check((plane_bytes != 0u ? voff : voff % g_nf_extent[1]) + 4u <= g_nf_extent[0], NFC_PIXEL, voff);
+    ok &= nf_check((unsigned long long)plane_bytes + voff + 4ull <= g_nf_extent[2], NFC_SLAB, voff);
+    return ok ? voff : 0u;
+}
 __device__ __forceinline__ float nf_ld(NfRsrc r, unsigned plane_bytes, unsigned voff)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, plane_bytes, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, nf_checked_off(plane_bytes, voff), plane_bytes, 0));
+}
+__device__ __forceinline__ unsigned nf_ld_u32(NfRsrc r, unsigned plane_bytes, unsigned voff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b32(r, nf_checked_off(plane_bytes, voff), plane_bytes, 0);
 }
 __device__ __forceinline__ void nf_st(NfRsrc r, unsigned plane_bytes, unsigned voff, float v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, plane_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, nf_checked_off(plane_bytes, voff), plane_bytes, 0);
 }
 
 // ofnltv_getD for one slot (src/global_faldoi.cpp:1145-1165): g = w (ubar_i - ubar_j) / wt;  p <- (p + tau g) / (1 + tau sqrt(g g))
@@ -191,10 +254,10 @@ __device__ __forceinline__ void nf_cross_compute(NfLds<TY> &L, const NfArgs &a, 
         if (c.need) {
             const int ry = c.jy - Y0 + kNlR, rx = c.jx - X0 + kNlR;
             const double rwt = recip_f64(cr.wt[r]);
-            const float pn = nl_dual_update(cr.p[r], cr.w[r], L.ub[0][ry][rx], L.ub[0][ry + c.k][rx + c.l], cr.wt[r], rwt, a.tau);
-            cr.q[r] = nl_dual_update(cr.q[r], cr.w[r], L.ub[1][ry][rx], L.ub[1][ry + c.k][rx + c.l], cr.wt[r], rwt, a.tau);
+            const float pn = nl_dual_update(cr.p[r], cr.w[r], L.ub_at(0, ry, rx), L.ub_at(0, ry + c.k, rx + c.l), cr.wt[r], rwt, a.tau);
+            cr.q[r] = nl_dual_update(cr.q[r], cr.w[r], L.ub_at(1, ry, rx), L.ub_at(1, ry + c.k, rx + c.l), cr.wt[r], rwt, a.tau);
             cr.at[r] = (c.s * (TY + 2 * kNlR) + ry) * kNfLW + rx;
-            (&L.pq[0][0][0])[cr.at[r]] = pn;
+            L.pq_flat(cr.at[r]) = pn;
         }
     }
 }
@@ -203,7 +266,7 @@ __device__ __forceinline__ void nf_cross_store_q(NfLds<TY> &L, const NfCrossRegs
 {
 #pragma unroll
     for (int r = 0; r < NfCrossRegs<TY>::rounds; ++r)
-        if (cr.at[r] >= 0) (&L.pq[0][0][0])[cr.at[r]] = cr.q[r];
+        if (cr.at[r] >= 0) L.pq_flat(cr.at[r]) = cr.q[r];
 }
 
 // The dual step of one flow component for the thread's own pixel: 24 slots in batches of kNlBatch.  A batch's loads are REQUESTED
@@ -221,7 +284,7 @@ __device__ __forceinline__ void nf_batch_loads(NfRsrc rs, unsigned pb, int d_old
 #pragma unroll
     for (int q = 0; q < kNlBatch; ++q) {
         b.p[q] = nf_ld(rs, (unsigned)(d_old + s0 + q) * pb, i4);
-        if (COMP == 0) b.w[q] = nf_ld(rs, (unsigned)(N_W + s0 + q) * pb, i4);
+        if (COMP == 0) b.w[q] = ((kNfWhatIf & 64) && s0 + q >= 12) ? 0.5f : nf_ld(rs, (unsigned)(N_W + s0 + q) * pb, i4);
     }
 }
 template <int TY, bool BORDER, int COMP>
@@ -229,7 +292,7 @@ __device__ __forceinline__ void nf_batch_update(NfLds<TY> &L, const NfArgs &a, N
                                                 unsigned i4, float wt, double rwt, const NfBatch &b, float (&wreg)[kNlSlots],
                                                 float (&preg)[kNlSlots], bool (&oks)[kNlSlots])
 {
-    const float ai = L.ub[COMP][ly + kNlR][lx + kNlR];
+    const float ai = L.ub_at(COMP, ly + kNlR, lx + kNlR);
     // (a slot that leaves the image is evaluated like the others -- its weight and its neighbour's ubar read as 0 -- but never
     // stored: such slots keep their duals, :1145, and the divergence skips them)
     float pb6[kNlBatch], wb6[kNlBatch], nb6[kNlBatch];
@@ -243,14 +306,14 @@ __device__ __forceinline__ void nf_batch_update(NfLds<TY> &L, const NfArgs &a, N
         }
         pb6[q] = b.p[q];
         wb6[q] = wreg[s];
-        nb6[q] = L.ub[COMP][ly + kNlR + nl_slot_k(s)][lx + kNlR + nl_slot_l(s)];
+        nb6[q] = L.ub_at(COMP, ly + kNlR + nl_slot_k(s), lx + kNlR + nl_slot_l(s));
     }
     nl_dual_update_n<kNlBatch>(pb6, wb6, ai, nb6, wt, rwt, a.tau);
 #pragma unroll
     for (int q = 0; q < kNlBatch; ++q) {
         const int s = s0 + q;
         if (!(kNfWhatIf & 16) && (!BORDER || oks[s])) nf_st(rs, (unsigned)(d_new + s) * pb, i4, pb6[q]);
-        L.pq[s][ly + kNlR][lx + kNlR] = pb6[q];
+        L.pq_at(s, ly + kNlR, lx + kNlR) = pb6[q];
         preg[s] = pb6[q];
     }
 }
@@ -274,14 +337,14 @@ __device__ __forceinline__ void nf_dual_own(NfLds<TY> &L, const NfArgs &a, NfRsr
 
 // non_local_divergence (:1056-1079) of one component from registers (own duals, weights) and LDS (mirror duals), slot order 0..23.
 template <int TY, bool BORDER>
-__device__ __forceinline__ float nf_divergence(const NfLds<TY> &L, int lx, int ly, const float (&wreg)[kNlSlots],
+__device__ __forceinline__ float nf_divergence(NfLds<TY> &L, int lx, int ly, const float (&wreg)[kNlSlots],
                                                const float (&preg)[kNlSlots], const bool (&oks)[kNlSlots])
 {
     float d = 0.0f;
 #pragma unroll
     for (int s = 0; s < kNlSlots; ++s) {
         const int k = nl_slot_k(s), l = nl_slot_l(s);
-        const float m = L.pq[kNlSlots - 1 - s][ly + kNlR + k][lx + kNlR + l];
+        const float m = L.pq_at(kNlSlots - 1 - s, ly + kNlR + k, lx + kNlR + l);
         const float nd = d + wreg[s] * (preg[s] - m);
         d = (!BORDER || oks[s]) ? nd : d;
     }
@@ -291,21 +354,24 @@ __device__ __forceinline__ float nf_divergence(const NfLds<TY> &L, int lx, int l
 // csad_select_ranked of nltv_kernels.hpp with the neighbours of I0 and I1w read from the staged LDS tiles: six probes per pixel.
 template <int TY> struct NfCsadFetch {
     const float *im;          // &L.im[0][ly][lx]: window position (k, l) = (-3, -3) of this pixel
+    int lx, ly;               // (check build only)
     __device__ __forceinline__ void operator()(unsigned e, bool, float &a0, float &a1) const
     {
         // (a probe that is not live carries a byte of the table all the same: 0 <= e <= 54, inside the staged tile)
-        const unsigned off = 9u * e - 8u * (e & 7u);
+        bool ok = nf_check((e >> 3) <= 2u * kCsR && (e & 7u) <= 2u * kCsR, NFC_RANK_BYTE, e);
+        ok = ok && nf_check(ly + (int)(e >> 3) < TY + 2 * kCsR && lx + (int)(e & 7u) < kNfW + 2 * kCsR, NFC_IM, e);
+        const unsigned off = ok ? 9u * e - 8u * (e & 7u) : 0u;
         a0 = im[off];
         a1 = im[off + (TY + 2 * kCsR) * kNfIW];
     }
 };
 template <int TY, bool BORDER>
-__device__ __forceinline__ float nf_csad_select(const NfLds<TY> &L, const unsigned (&rk)[kCsRankWords], int lx, int ly, int x, int y, int nx,
+__device__ __forceinline__ float nf_csad_select(NfLds<TY> &L, const unsigned (&rk)[kCsRankWords], int lx, int ly, int x, int y, int nx,
                                                 int ny, float t1, float t2, float r, float sg, double rsg, float l_t)
 {
-    const float i0 = L.im[0][ly + kCsR][lx + kCsR], i1w = L.im[1][ly + kCsR][lx + kCsR];
+    const float i0 = L.im_at(0, ly + kCsR, lx + kCsR), i1w = L.im_at(1, ly + kCsR, lx + kCsR);
     const int n = BORDER ? csad_valid_count(x, y, nx, ny) : kCsSlots;
-    return csad_select_ranked<!BORDER>(rk, n, NfCsadFetch<TY>{ &L.im[0][ly][lx] }, i0, i1w, t1, t2, r, sg, rsg, l_t);
+    return csad_select_ranked<!BORDER>(rk, n, NfCsadFetch<TY>{ &L.im[0][ly][lx], lx, ly }, i0, i1w, t1, t2, r, sg, rsg, l_t);
 }
 
 typedef float nf_f4 __attribute__((ext_vector_type(4)));
@@ -330,7 +396,9 @@ __device__ __forceinline__ NfQuad nf_stage_load(NfRsrc rs, unsigned pb, int plan
     // resource, which returns 0); those components are zeroed below.
     const bool lead = gx < 0;                                          // then gx == -RING
     const unsigned off = row ? (unsigned)(plane0 + comp) * pb + 4u * (unsigned)(gy * nx + (lead ? 0 : gx)) : 0u;
-    const nf_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0u, 0);
+    // (check build: a quad may run past its row -- masked below -- but never past the slab)
+    const bool inside = nf_check(!kNfCheck || (unsigned long long)off + 16ull <= g_nf_extent[2], NFC_SLAB, off);
+    const nf_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, inside ? off : 0u, 0u, 0);
     NfQuad q;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -384,15 +452,20 @@ __device__ __forceinline__ void nl_fused_body(const NfArgs &a, NfLds<TY> &L, int
         c0 = nf_ld(rs, (unsigned)N_T1 * pb, i4);
         c1 = nf_ld(rs, (unsigned)N_T2 * pb, i4);
 #pragma unroll
-        for (int w = 0; w < kCsRankWords; ++w) rk[w] = __builtin_amdgcn_raw_buffer_load_b32(rs, i4, (unsigned)(N_RK + w) * pb, 0);
+        for (int w = 0; w < kCsRankWords; ++w)
+            rk[w] = ((kNfWhatIf & 128) && w >= 9) ? 0x09090909u : nf_ld_u32(rs, (unsigned)(N_RK + w) * pb, i4);
     }
     NfBatch bp0;
     nf_batch_loads<0>(rs, pb, p_old, 0, i4, bp0);
+    NfCrossRegs<TY> cr;
+    if (!(kNfWhatIf & 2)) nf_cross_loads<TY>(a, rs, pb, p_old, q_old, X0, Y0, cr);       // in flight during the data step and the own slots
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- stage ubar (ring 2) and I0 / I1w (ring 3)
-    if (sq_ub.lds >= 0) *reinterpret_cast<nf_f4 *>(&L.ub[0][0][0] + sq_ub.lds) = sq_ub.v;
-    if (!DATA_L1 && sq_im.lds >= 0) *reinterpret_cast<nf_f4 *>(&L.im[0][0][0] + sq_im.lds) = sq_im.v;
+    if (sq_ub.lds >= 0 && nf_check(sq_ub.lds + 4 <= 2 * (TY + 2 * kNlR) * kNfLW && (sq_ub.lds & 3) == 0, NFC_STAGE_LDS, (unsigned)sq_ub.lds))
+        *reinterpret_cast<nf_f4 *>(&L.ub[0][0][0] + sq_ub.lds) = sq_ub.v;
+    if (!DATA_L1 && sq_im.lds >= 0 && nf_check(sq_im.lds + 4 <= 2 * (TY + 2 * kCsR) * kNfIW && (sq_im.lds & 3) == 0, NFC_STAGE_LDS, (unsigned)sq_im.lds))
+        *reinterpret_cast<nf_f4 *>(&L.im[0][0][0] + sq_im.lds) = sq_im.v;
     const double rwt = recip_f64(wt);            // wt > 0 (every pixel has valid neighbours): shared by 48 quotients
     __syncthreads();
 
@@ -420,8 +493,6 @@ __device__ __forceinline__ void nl_fused_body(const NfArgs &a, NfLds<TY> &L, int
 
     float wreg[kNlSlots], preg[kNlSlots];
     bool oks[kNlSlots];
-    NfCrossRegs<TY> cr;
-    if (!(kNfWhatIf & 2)) nf_cross_loads<TY>(a, rs, pb, p_old, q_old, X0, Y0, cr);       // in flight while the own slots are computed
     nf_dual_own<TY, BORDER, 0>(L, a, rs, pb, p_old, p_new, x, y, lx, ly, i4, in, wt, rwt, bp0, wreg, preg, oks);
     NfBatch bq0;
     nf_batch_loads<1>(rs, pb, q_old, 0, i4, bq0);                        // the second component's first batch: in flight across the
@@ -452,6 +523,21 @@ __global__ __launch_bounds__(kNfW * TY) void nl_fused_kernel(NfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char nf_lds_raw[];
     NfLds<TY> &L = *reinterpret_cast<NfLds<TY> *>(nf_lds_raw);
+    if (kNfCheck) {                                // (every workgroup writes the same three values; the host zeroes g_nf_check)
+        g_nf_extent[0] = 4u * (unsigned)(a.nx * a.ny);
+        g_nf_extent[1] = 4u * (unsigned)a.pe;
+        g_nf_extent[2] = 4u * (unsigned)a.pe * (unsigned)N_COUNT;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicAdd(&g_nf_check[3], 1u);
+            if (a.check_selftest) {
+                (void)L.pq_at(kNlSlots, 0, 0);
+                (void)L.ub_at(0, TY + 2 * kNlR, 0);
+                (void)L.im_at(1, 0, kNfW + 2 * kCsR);
+                (void)L.pq_flat(kNlSlots * (TY + 2 * kNlR) * kNfLW);
+                (void)nf_checked_off(4u * (unsigned)a.pe, 4u * (unsigned)(a.nx * a.ny));
+            }
+        }
+    }
     // XCD-aware tile order: blocks are dealt to the 8 XCDs round-robin, so XCD k gets the `per` consecutive tiles [k per, (k+1) per)
     // (neighbouring tiles re-read each other's ring from one L2), block j of the XCD takes the j-th of them.  Among those the tiles on
     // the image frame go FIRST: they are the slower ones (stencil validity selects), and the grid runs in rounds of one tile per CU --

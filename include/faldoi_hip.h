@@ -96,6 +96,11 @@ int faldoi_ctx_persist_retry(faldoi_ctx *ctx);
  * turned out to be an even integer >= 6 -- possible only for images that were not normalised to [0, 1] (faldoi_device.hpp: div_once;
  * the result is the reference's either way, the repeat costs one solve and happens once per upload). */
 int faldoi_ctx_exact_redos(faldoi_ctx *ctx, long *redos);
+/* Diagnostic of the fused NLTV kernel's range-checked build (libfaldoi_hip_check.so, compiled with -DFALDOI_NL_CHECK=1; see
+ * csrc/nltv_fused_kernel.hpp, nf_check): out[0] = bit per kind of index that left its extent, out[1] = number of violations,
+ * out[2] = largest offending value, out[3] = launches checked; reset != 0 clears the words afterwards.  *compiled_in = 1 only in
+ * the check build -- in the product library the checks do not exist and the words stay 0. */
+int faldoi_debug_nl_check(faldoi_ctx *ctx, unsigned out[4], int reset, int *compiled_in);
 /* Thread-local text of the last failure (HIP error string, argument that was rejected). */
 const char *faldoi_last_error(void);
 void faldoi_tvl1_default_params(faldoi_tvl1_params *p);

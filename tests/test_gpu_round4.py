@@ -102,3 +102,34 @@ def test_csad_selection_by_ranks_equals_the_sorting_network_and_the_checker(ctx,
             assert np.array_equal(got, want), (case, w, h, mismatch_report(got, want))
             checked += 1
     assert checked >= 8
+
+
+def test_fused_nltv_kernel_range_checked_build_is_clean(ctx):
+    """libfaldoi_hip_check.so (build.build_check(): the same sources with -DFALDOI_NL_CHECK=1) compares every LDS index and every slab
+    offset the fused NLTV kernel forms with the extent it must stay inside (nltv_fused_kernel.hpp, nf_check).  The geometry sweep
+    of the fused-kernel tests -- images smaller than a tile, ragged last tiles, one to seven tile columns, every tile height, both
+    data terms -- and the full frame run on it ONCE, in a child process: no violation, the same flows as the product build, and the
+    detector is shown not to be vacuous (a deliberate out-of-range index of each kind is reported)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    so = F.build.SO_CHECK
+    assert os.path.exists(so), "range-checked library missing: __graft_entry__.build() makes it"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "nl_check_run.py")
+    env = dict(os.environ, FALDOI_LIB=so)
+    env.pop("FALDOI_NL_FUSED", None)
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["compiled_in"] and rep["library"].endswith("libfaldoi_hip_check.so")
+    assert rep["launches"] > 500, rep
+    assert rep["bits"] == 0 and rep["violations"] == 0, rep
+    assert rep["selftest_violations"] >= 5 and bin(rep["selftest_bits"]).count("1") >= 4, rep
+    # the same sweep on the product library (this process): identical flows
+    r2 = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=900,
+                        env={k: v for k, v in os.environ.items() if k != "FALDOI_LIB"})
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    rep2 = json.loads(r2.stdout.strip().splitlines()[-1])
+    assert not rep2["compiled_in"] and rep2["bits"] == 0 and rep2["sha256"] == rep["sha256"], (rep, rep2)
