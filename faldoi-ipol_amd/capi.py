@@ -18,7 +18,7 @@ MAX_CHUNK = 16
 # every symbol include/faldoi_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "faldoi_abi_version", "faldoi_device_count", "faldoi_ctx_create", "faldoi_ctx_destroy",
-    "faldoi_ctx_synchronize", "faldoi_ctx_persist_stats", "faldoi_ctx_persist_retry", "faldoi_ctx_exact_redos", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
+    "faldoi_ctx_synchronize", "faldoi_ctx_persist_stats", "faldoi_ctx_persist_retry", "faldoi_ctx_exact_redos", "faldoi_debug_nl_check", "faldoi_ctx_last_transfer_ms", "faldoi_last_error", "faldoi_tvl1_default_params", "faldoi_tvl1_global",
     "faldoi_tvl1_batch_create", "faldoi_tvl1_batch_destroy", "faldoi_tvl1_batch_upload",
     "faldoi_tvl1_batch_reset", "faldoi_tvl1_batch_solve", "faldoi_tvl1_batch_download",
     "faldoi_tvl1_batch_last_timing", "faldoi_tvl1_batch_last_schedule", "faldoi_tvl1_batch_last_persistent", "faldoi_tvl1_schedule_query", "faldoi_centered_gradient", "faldoi_forward_gradient",
@@ -120,6 +120,7 @@ def lib():
     L.faldoi_ctx_persist_stats.argtypes = [vp] + [C.POINTER(C.c_long)] * 4
     L.faldoi_ctx_persist_retry.argtypes = [vp]
     L.faldoi_ctx_exact_redos.argtypes = [vp, C.POINTER(C.c_long)]
+    L.faldoi_ctx_last_transfer_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.faldoi_debug_nl_check.argtypes = [vp, C.POINTER(C.c_uint * 4), C.c_int, C.POINTER(C.c_int)]
     L.faldoi_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
     L.faldoi_tvl1_default_params.restype = None
@@ -200,6 +201,15 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _as(a, shape, name):
+    """float32, C-contiguous, and of exactly `shape`: the C ABI takes raw pointers and ONE (nx, ny), so an array of another size
+    would be read (or written) past its end inside the library -- a segmentation fault of the host process, with no message."""
+    a = _f32(a)
+    if a.shape != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return a
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -238,6 +248,12 @@ class Context:
     def persist_retry(self):
         _check(lib().faldoi_ctx_persist_retry(self._h))
 
+    def last_transfer_ms(self):
+        """(h2d_ms, d2h_ms): host wall time of this context's last batch upload / download (inside tvl1_global too)."""
+        a, b = C.c_double(0), C.c_double(0)
+        _check(lib().faldoi_ctx_last_transfer_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def exact_redos(self):
         """Solves repeated with the general quotients (a divisor was an even integer >= 6: images that were not normalised)."""
         n = C.c_long(0)
@@ -260,31 +276,35 @@ class Context:
         return fx, fy
 
     def divergence(self, v1, v2):
-        v1, v2 = _f32(v1), _f32(v2)
+        v1 = _f32(v1)
         h, w = v1.shape
+        v2 = _as(v2, (h, w), "v2")
         d = np.empty_like(v1)
         _check(lib().faldoi_divergence(self._h, v1, v2, d, w, h))
         return d
 
     def bicubic_warp(self, img, u, v, border_out=True):
-        img, u, v = _f32(img), _f32(u), _f32(v)
+        img = _f32(img)
         h, w = img.shape
+        u, v = _as(u, (h, w), "u"), _as(v, (h, w), "v")
         o = np.empty_like(img)
         _check(lib().faldoi_bicubic_warp(self._h, img, u, v, o, w, h, int(bool(border_out))))
         return o
 
     def preprocess_global(self, i0, i1, im1=None):
         """(pd,h,w) planar images 0..255 -> (i0n, i1n) as the solver takes them (GPU)."""
-        i0, i1 = _f32(i0), _f32(i1)
-        im1 = None if im1 is None else _f32(im1)
+        i0 = _f32(i0)
         pd, h, w = i0.shape
+        i1 = _as(i1, (pd, h, w), "i1")
+        im1 = None if im1 is None else _as(im1, (pd, h, w), "im1")
         o0, o1 = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
         _check(lib().faldoi_preprocess_global(self._h, i0, i1, _ptr(im1), w, h, pd, o0, o1))
         return o0, o1
 
     def preprocess_local(self, i0, i1):
         """prepare_stuff's image part of the local step: (pd,h,w) or (h,w) frames -> normalised (h,w) pair."""
-        i0, i1 = _f32(i0), _f32(i1)
+        i0 = _f32(i0)
+        i1 = _as(i1, i0.shape, "i1")
         pd = 1 if i0.ndim == 2 else i0.shape[0]
         h, w = i0.shape[-2:]
         o0, o1 = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
@@ -293,10 +313,11 @@ class Context:
 
     def tvcsad_global(self, i0n, i1n, u0, xi=None, **params):
         """Mirror of tvcsad_PD (one-thread stop test).  Returns (u, iters[warps], err[warps], xi, stats)."""
-        i0n, i1n = _f32(i0n), _f32(i1n)
+        i0n = _f32(i0n)
         h, w = i0n.shape
-        u = _f32(u0).copy()
-        xi = np.zeros((4, h, w), np.float32) if xi is None else _f32(xi).copy()
+        i1n = _as(i1n, (h, w), "i1n")
+        u = _as(u0, (2, h, w), "u0").copy()
+        xi = np.zeros((4, h, w), np.float32) if xi is None else _as(xi, (4, h, w), "xi").copy()
         p = Tvl1Params()
         lib().faldoi_tvcsad_default_params(C.byref(p))
         for k, v in params.items():
@@ -320,8 +341,9 @@ class Context:
 
     def fb_consistency_check(self, in0, in1, epsilon=2.0):
         """Mirror of fb_consistency_check: (2,h,w) forward / backward flows -> trust (h,w) int32."""
-        in0, in1 = _f32(in0), _f32(in1)
+        in0 = _f32(in0)
         h, w = in0.shape[1:]
+        in0, in1 = _as(in0, (2, h, w), "in0"), _as(in1, (2, h, w), "in1")
         trust = np.empty((h, w), np.int32)
         _check(lib().faldoi_fb_consistency_check(self._h, in0, in1, w, h, epsilon, trust, None))
         return trust
@@ -386,9 +408,13 @@ class Context:
         return outs, enes, st
 
     def _nl_global(self, defaults, solve, i0n, i1n, lab, u0, params):
-        i0n, i1n, lab = _f32(i0n), _f32(i1n), _f32(lab)
+        i0n, lab = _f32(i0n), _f32(lab)
         h, w = i0n.shape
-        u = _f32(u0).copy()
+        i1n = _as(i1n, (h, w), "i1n")
+        if lab.ndim != 3:
+            raise ValueError("lab must be (pd,h,w), got %s" % (lab.shape,))
+        lab = _as(lab, (lab.shape[0], h, w), "lab")
+        u = _as(u0, (2, h, w), "u0").copy()
         p = NltvCsadParams()
         defaults(C.byref(p))
         for k, v in params.items():
@@ -440,10 +466,11 @@ class Context:
 
     # ---- one-call solver (mirror of tvl2OF) ----
     def tvl1_global(self, i0n, i1n, u0, xi=None, **params):
-        i0n, i1n = _f32(i0n), _f32(i1n)
+        i0n = _f32(i0n)
         h, w = i0n.shape
-        u = _f32(u0).copy()
-        xi = None if xi is None else _f32(xi).copy()
+        i1n = _as(i1n, (h, w), "i1n")
+        u = _as(u0, (2, h, w), "u0").copy()
+        xi = None if xi is None else _as(xi, (4, h, w), "xi").copy()
         p = default_params(**params)
         iters = np.zeros(p.warps, np.int32)
         errs = np.zeros(p.warps, np.float32)
@@ -473,15 +500,21 @@ class Tvl1Batch:
             pass
 
     def upload(self, pair, i0n, i1n, u0, xi=None):
-        xi = None if xi is None else _f32(xi)
-        _check(lib().faldoi_tvl1_batch_upload(self._h, int(pair), _f32(i0n), _f32(i1n), _f32(u0), _ptr(xi)))
+        hw = (self.h, self.w)
+        xi = None if xi is None else _as(xi, (4,) + hw, "xi")
+        _check(lib().faldoi_tvl1_batch_upload(self._h, int(pair), _as(i0n, hw, "i0n"), _as(i1n, hw, "i1n"), _as(u0, (2,) + hw, "u0"), _ptr(xi)))
 
     def upload_images(self, pair, i0, i1, u0, im1=None, xi=None):
-        i0, i1 = _f32(i0), _f32(i1)
-        im1 = None if im1 is None else _f32(im1)
-        xi = None if xi is None else _f32(xi)
+        i0 = _f32(i0)
+        hw = (self.h, self.w)
+        if i0.ndim != 3:
+            raise ValueError("i0 must be (pd,h,w), got %s" % (i0.shape,))
+        i0 = _as(i0, (i0.shape[0],) + hw, "i0")
+        i1 = _as(i1, i0.shape, "i1")
+        im1 = None if im1 is None else _as(im1, i0.shape, "im1")
+        xi = None if xi is None else _as(xi, (4,) + hw, "xi")
         _check(lib().faldoi_tvl1_batch_upload_images(self._h, int(pair), i0, i1, _ptr(im1), i0.shape[0],
-                                                     _f32(u0), _ptr(xi)))
+                                                     _as(u0, (2,) + hw, "u0"), _ptr(xi)))
 
     def solve(self, **params):
         p = default_params(**params)
@@ -541,6 +574,8 @@ def queue_replay(ops, sims):
 def image_to_lab(rgb):
     """(3,h,w) planar RGB 0..255 -> planar Lab (host side of the library, libm)."""
     rgb = _f32(rgb)
+    if rgb.ndim != 3 or rgb.shape[0] != 3:
+        raise ValueError("image_to_lab takes (3,h,w) planar RGB, got %s" % (rgb.shape,))
     out = np.empty_like(rgb)
     _check(lib().faldoi_image_to_lab(rgb, rgb.shape[2], rgb.shape[1], out))
     return out
@@ -550,8 +585,9 @@ class LocalTvl1:
     """The local TV-l2 coupled patch operator (faldoi_local_tvl1): device-resident flow, duals, divergence."""
 
     def __init__(self, ctx, i0n, i1n):
-        i0n, i1n = _f32(i0n), _f32(i1n)
+        i0n = _f32(i0n)
         self.h, self.w = i0n.shape
+        i1n = _as(i1n, i0n.shape, "i1n")
         self._ctx = ctx
         self._h = C.c_void_p()
         _check(lib().faldoi_local_tvl1_create(ctx._h, i0n, i1n, self.w, self.h, C.byref(self._h)))
@@ -568,7 +604,7 @@ class LocalTvl1:
             pass
 
     def set_flow(self, u):
-        _check(lib().faldoi_local_tvl1_set_flow(self._h, _f32(u)))
+        _check(lib().faldoi_local_tvl1_set_flow(self._h, _as(u, (2, self.h, self.w), "u")))
 
     def get_flow(self):
         u = np.empty((2, self.h, self.w), np.float32)
@@ -576,7 +612,10 @@ class LocalTvl1:
         return u
 
     def set_fixed(self, fixed):
-        _check(lib().faldoi_local_tvl1_set_fixed(self._h, np.ascontiguousarray(fixed, np.int32)))
+        fixed = np.ascontiguousarray(fixed, np.int32)
+        if fixed.shape != (self.h, self.w):
+            raise ValueError("fixed has shape %s, expected %s" % (fixed.shape, (self.h, self.w)))
+        _check(lib().faldoi_local_tvl1_set_fixed(self._h, fixed))
 
     def interpolate(self, patches):
         patches = np.ascontiguousarray(np.asarray(patches, np.int32).reshape(-1, 4))

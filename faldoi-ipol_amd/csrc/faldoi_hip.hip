@@ -128,6 +128,9 @@ struct faldoi_ctx {
     long persist_backed_off = 0;      // solves kept off it while backing off after a give-up
     int persist_backoff = 0;          // such solves still to come before the persistent path is tried again
     int persist_backoff_len = 0;      // length of the current back-off: 16, doubling per consecutive give-up up to 1024; 0 = none
+    // Host wall time of the last batch upload / download on this context (copies from / to the caller's pageable buffers plus the
+    // synchronisation), faldoi_ctx_last_transfer_ms: what SURVEY 8d asks to be reported beside the solver's device time
+    double last_h2d_ms = 0.0, last_d2h_ms = 0.0;
 };
 
 // ------------------------------------------------------------------------------------------ who else is on the device
@@ -565,6 +568,7 @@ static int faldoi_tvl1_batch_upload_impl(faldoi_tvl1_batch *b, int pair, const f
     HIP_TRY(hipSetDevice(b->ctx->device));
     hipStream_t s = b->ctx->stream;
     const size_t n = (size_t)b->nx * b->ny, nb = n * sizeof(float);
+    const auto t_up = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(plane_ptr(b, pair, P_I0), I0, nb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(plane_ptr(b, pair, P_I1), I1, nb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(plane_ptr(b, pair, P_INIT + 0), u, nb, hipMemcpyHostToDevice, s));
@@ -576,6 +580,7 @@ static int faldoi_tvl1_batch_upload_impl(faldoi_tvl1_batch *b, int pair, const f
             HIP_TRY(hipMemsetAsync(plane_ptr(b, pair, P_INIT + 2 + k), 0, nb, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
+    b->ctx->last_h2d_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up).count();
     b->uploaded[pair] = 1;
     b->exact_quot = false;
     b->solved = false;
@@ -1018,12 +1023,22 @@ extern "C" int faldoi_tvl1_batch_download(faldoi_tvl1_batch *b, int pair, float 
     hipStream_t s = b->ctx->stream;
     const size_t n = (size_t)b->nx * b->ny, nb = n * sizeof(float);
     const int st = b->final_cur[pair] ? P_STATE1 : P_STATE0;
+    const auto t_down = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(u, plane_ptr(b, pair, st + 0), nb, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(u + n, plane_ptr(b, pair, st + 1), nb, hipMemcpyDeviceToHost, s));
     if (xi)
         for (int k = 0; k < 4; ++k)
             HIP_TRY(hipMemcpyAsync(xi + k * n, plane_ptr(b, pair, st + 4 + k), nb, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    b->ctx->last_d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_down).count();
+    return FALDOI_OK;
+}
+
+extern "C" int faldoi_ctx_last_transfer_ms(faldoi_ctx *c, double *h2d_ms, double *d2h_ms)
+{
+    if (!c) return fail(FALDOI_ERR_INVALID, "ctx is NULL");
+    if (h2d_ms) *h2d_ms = c->last_h2d_ms;
+    if (d2h_ms) *d2h_ms = c->last_d2h_ms;
     return FALDOI_OK;
 }
 
@@ -1242,6 +1257,7 @@ static int faldoi_tvl1_batch_upload_images_impl(faldoi_tvl1_batch *b, int pair, 
     int rc = preprocess_check(c, i0, i1, b->nx, b->ny, pd);
     if (rc) return rc;
     const size_t n = (size_t)b->nx * b->ny, nb = n * sizeof(float);
+    const auto t_up = std::chrono::steady_clock::now();                 // (here "H2D" includes the device-side preprocessing)
     float *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, sizeof(float) * (5 * n + 6 * 1026)));
     float *C = d, *tmp = d + n, *staging = d + 2 * n, *part = d + 5 * n;
@@ -1264,6 +1280,7 @@ static int faldoi_tvl1_batch_upload_images_impl(faldoi_tvl1_batch *b, int pair, 
     if (rc) return rc;
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(FALDOI_ERR_HIP, "upload failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    c->last_h2d_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up).count();
     b->uploaded[pair] = 1;
     b->exact_quot = false;
     b->solved = false;

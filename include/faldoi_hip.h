@@ -96,6 +96,10 @@ int faldoi_ctx_persist_retry(faldoi_ctx *ctx);
  * turned out to be an even integer >= 6 -- possible only for images that were not normalised to [0, 1] (faldoi_device.hpp: div_once;
  * the result is the reference's either way, the repeat costs one solve and happens once per upload). */
 int faldoi_ctx_exact_redos(faldoi_ctx *ctx, long *redos);
+/* Host wall time (ms) of this context's last faldoi_tvl1_batch_upload (also inside faldoi_tvl1_global) and faldoi_tvl1_batch_download:
+ * the copies from / to the caller's buffers and their synchronisation -- the H2D / D2H figures SURVEY 8d asks to be reported beside
+ * the solver's device time (faldoi_tvl1_stats.solve_ms never includes them). */
+int faldoi_ctx_last_transfer_ms(faldoi_ctx *ctx, double *h2d_ms, double *d2h_ms);
 /* Diagnostic of the fused NLTV kernel's range-checked build (libfaldoi_hip_check.so, compiled with -DFALDOI_NL_CHECK=1; see
  * csrc/nltv_fused_kernel.hpp, nf_check): out[0] = bit per kind of index that left its extent, out[1] = number of violations,
  * out[2] = largest offending value, out[3] = launches checked; reset != 0 clears the words afterwards.  *compiled_in = 1 only in

@@ -122,3 +122,35 @@ def test_candidate_queue_pops_like_std_priority_queue(oracle):
                 want.append(i.value if L.orc_queue_pop(q, C.byref(i), C.byref(j), C.byref(u), C.byref(v), C.byref(s)) else -1)
         L.orc_queue_free(q)
         assert list(got) == want, (levels, n)
+
+
+def test_binding_rejects_arrays_of_the_wrong_shape_before_the_library_sees_them():
+    """The C ABI takes raw pointers and one (nx, ny): a frame, flow or Lab image of another size would be read past its end
+    inside the library -- the host process dies of a segmentation fault without a message (the unexplained core dump of a
+    round-3 scratch script, gpurun_out/nl_cases.log, fits exactly that: no GPU fault line, no exception text, at the script's
+    first randomly cropped case).  The ctypes binding therefore checks every array against the frame's shape; no GPU needed."""
+    i0 = np.zeros((20, 30), np.float32)
+    lab = np.zeros((3, 20, 30), np.float32)
+    u0 = np.zeros((2, 20, 30), np.float32)
+
+    class Stub(F.capi.Context):                       # no device: the checks run before the library is called
+        def __init__(self):
+            self._h = None
+
+        def close(self):
+            pass
+    c = Stub()
+    with pytest.raises(ValueError, match="i1n has shape"):
+        c.nltvcsad_global(i0, np.zeros((20, 31), np.float32), lab, u0)
+    with pytest.raises(ValueError, match="lab has shape"):
+        c.nltvcsad_global(i0, i0, np.zeros((3, 21, 30), np.float32), u0)
+    with pytest.raises(ValueError, match="u0 has shape"):
+        c.nltvl1_global(i0, i0, lab, np.zeros((2, 20, 29), np.float32))
+    with pytest.raises(ValueError, match="u0 has shape"):
+        c.tvl1_global(i0, i0, np.zeros((2, 19, 30), np.float32))
+    with pytest.raises(ValueError, match="xi has shape"):
+        c.tvcsad_global(i0, i0, u0, xi=np.zeros((4, 20, 31), np.float32))
+    with pytest.raises(ValueError, match="i1 has shape"):
+        c.preprocess_global(np.zeros((3, 20, 30), np.float32), np.zeros((3, 20, 31), np.float32))
+    with pytest.raises(ValueError, match="planar RGB"):
+        F.capi.image_to_lab(np.zeros((20, 30), np.float32))

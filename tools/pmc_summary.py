@@ -71,6 +71,7 @@ def main():
     a = ap.parse_args()
     want_grid = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.grid}
     acc = {}                                      # family -> counter -> [sum, count]
+    durs = {}                                     # family -> every kernel-trace duration of the duration pass (ns)
     meta = {}
     pmc_passes = 0
     for d in a.dirs:
@@ -99,6 +100,7 @@ def main():
                             s = acc.setdefault(fam, {}).setdefault("_dur_ns", [0.0, 0])
                             s[0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
                             s[1] += 1
+                            durs.setdefault(fam, []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
     out = {"_label": a.label, "_source": [os.path.relpath(d) for d in a.dirs], "_pmc_passes": pmc_passes,
            "_source_hash": source_hash()}
     for fam, counters in acc.items():
@@ -107,6 +109,11 @@ def main():
             if c == "_dur_ns":
                 e["avg_us"] = round(tot / n / 1e3, 3)
                 e["launches_timed"] = n
+                d = sorted(durs.get(fam, []))
+                if d:                             # the median is what bench.py compares its live duration with (a mean is pulled up by
+                    e["median_us"] = round((d[(len(d) - 1) // 2] + d[len(d) // 2]) / 2e3, 3)   # the odd slow launch and the profiler)
+                    e["min_us"] = round(d[0] / 1e3, 3)
+                    e["max_us"] = round(d[-1] / 1e3, 3)
             elif c in KB_COUNTERS:
                 e[c + "_KB"] = round(tot / n, 3)
             else:
