@@ -54,11 +54,16 @@ class Tvl1Stats(C.Structure):
                 ("solve_ms", C.c_double), ("chunk_launches", C.c_int)]
 
 
+# faldoi_local_params::partial_cb (user, pair, percent, iteration, part_idx, w, h, flow)
+PARTIAL_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float))
+
+
 class LocalParams(C.Structure):
     _fields_ = [("w_radio", C.c_int), ("iterations_of", C.c_int), ("max_iter_patch", C.c_int), ("epsilon", C.c_float),
                 ("preprocessed", C.c_int), ("budget", C.c_int), ("verbose", C.c_int), ("method", C.c_int),
                 ("split_img", C.c_int), ("h_parts", C.c_int), ("v_parts", C.c_int),
-                ("first_h_parts", C.c_int), ("first_v_parts", C.c_int)]
+                ("first_h_parts", C.c_int), ("first_v_parts", C.c_int),
+                ("partial_cb", PARTIAL_CB), ("partial_user", C.c_void_p)]
 
 
 class LocalStats(C.Structure):
@@ -353,6 +358,16 @@ class Context:
         p = LocalParams()
         lib().faldoi_local_default_params(C.byref(p))
         for k, v in params.items():
+            if k == "partial_res":
+                # -partial_res 1: `v` is a dict that receives {(pair, percent, iteration, part_idx): flow (2,h,w)} (or a falsy value)
+                if v is not None and v is not False:
+                    sink = v
+
+                    def keep(_user, pair, percent, iteration, part_idx, w, h, flow, sink=sink):
+                        sink[(pair, percent, iteration, part_idx)] = np.ctypeslib.as_array(flow, shape=(2, h, w)).copy()
+                    p.partial_cb = PARTIAL_CB(keep)
+                    p._keepalive = p.partial_cb                     # the C side holds a bare pointer during the call
+                continue
             setattr(p, {"wr": "w_radio", "loc_it": "iterations_of", "fb_thresh": "epsilon"}.get(k, k), v)
         return p
 

@@ -4,7 +4,7 @@
 //
 //   local_faldoi ims.txt in0.flo in1.flo out.flo sim_map [sal0 sal1]
 //                [-m method] [-wr radius] [-p params.txt] [-loc_it n] [-max_pch_it n] [-split_img 0]
-//                [-h_parts n] [-v_parts n] [-fb_thresh t] [-partial_res 0] [-verbose 0|1]
+//                [-h_parts n] [-v_parts n] [-fb_thresh t] [-partial_res 0|1] [-verbose 0|1]
 //   additive flags: [-gpu id] [-budget windows_per_launch]
 //
 // ims.txt: I0, I1 [, I-1, I2]; three lines are an error (:1852-1860); the extra frames only matter to
@@ -55,6 +55,27 @@ static void write_sim_map(const std::string &path, const float *e, int w, int h)
     fclose(f);
 }
 
+namespace {
+struct PartialSink {
+    std::string dir;
+    bool split;
+    static void write(void *user, int /*pair*/, int percent, int iteration, int part_idx, int w, int h, const float *flow)
+    {
+        const PartialSink &me = *static_cast<const PartialSink *>(user);
+        std::string name = me.dir;
+        if (!name.empty() && name.back() != '/') name += '/';
+        name += "partial_results_fwd_" + std::to_string(percent) + "_iter_" + std::to_string(iteration);
+        if (me.split) name += "_part_idx" + std::to_string(part_idx);
+        name += ".flo";
+        try {
+            write_flo(name, flow, w, h);
+        } catch (const std::exception &e) {                   // (the reference's writer aborts the program here; a partial result is
+            fprintf(stderr, "warning: %s\n", e.what());       // a by-product: say so and go on)
+        }
+    }
+};
+}  // namespace
+
 int main(int argc, char *argv[])
 {
     try {
@@ -71,6 +92,8 @@ int main(int argc, char *argv[])
         const int first_v_parts = std::stoi(pick_option(args, "first_v_parts", "0"));
         const float fb_thresh = std::stof(pick_option(args, "fb_thresh", "2"));
         const int partial_res = std::stoi(pick_option(args, "partial_res", "0"));
+        // additive: where -partial_res 1 writes (the reference's fixed place, relative to the working directory, :950)
+        const std::string partial_dir = pick_option(args, "partial_dir", "../Results/Partial_results/");
         const int verbose = std::stoi(pick_option(args, "verbose", "0"));
         const int gpu = std::stoi(pick_option(args, "gpu", "0"));
         const int budget = std::stoi(pick_option(args, "budget", "0"));
@@ -84,7 +107,6 @@ int main(int argc, char *argv[])
                             "model -m 8 is not built)\n", method);
             return 2;
         }
-        if (partial_res != 0) fprintf(stderr, "warning: -partial_res is ignored (no partial results are written)\n");
 
         std::vector<std::string> files;
         {
@@ -135,6 +157,11 @@ int main(int argc, char *argv[])
         prm.verbose = verbose; prm.method = method; prm.split_img = split_img; prm.h_parts = h_parts; prm.v_parts = v_parts;
         prm.first_h_parts = first_h_parts; prm.first_v_parts = first_v_parts;
         if (budget > 0) prm.budget = budget;
+        // -partial_res 1 (src/local_faldoi.cpp:942-1036): the forward growings' flow at 30 / 70 / 80 / 95 / 100 % of their pixels,
+        // under the reference's names -- "_part_idx<k>" is appended whenever -split_img is on, whole-image growings included
+        // (k = -1 inside the iterations, the iteration number for the last growing, as the reference passes it)
+        PartialSink sink{ partial_dir, split_img != 0 };
+        if (partial_res == 1) { prm.partial_cb = &PartialSink::write; prm.partial_user = &sink; }
         faldoi_ctx *ctx = nullptr;
         if (faldoi_ctx_create(gpu, &ctx)) { fprintf(stderr, "ERROR: no usable GPU: %s\n", faldoi_last_error()); return 3; }
         std::vector<float> out(2 * n), ene(n);

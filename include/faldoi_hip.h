@@ -299,6 +299,14 @@ typedef struct faldoi_local_params {
     int v_parts;          /* -v_parts, VER_PARTS 2 (:70) */
     int first_h_parts;    /* split_img 2 only (additive): grid of local iteration 0, first_h_parts x first_v_parts; */
     int first_v_parts;    /* 0 = the transposed grid, like every even iteration.  A coarse first grid keeps most of the accuracy */
+    /* -partial_res 1 (src/local_faldoi.cpp:942-1036): every FORWARD growing hands out its flow the first time the share of pixels it
+     * has fixed passes 30 / 70 / 80 / 95 % (the reference's test, `percent > P[k] && percent < P[k+1]` on a float percentage, so a
+     * threshold can be skipped on tiny domains) and once more when its queue is empty (percent = 100).  flow: 2 planes of w*h, valid
+     * during the call; part_idx as the reference passes it to local_growing (-1 whole image inside the iterations, the partition's
+     * index, the iteration number for the last whole-image growing).  The executable writes the reference's file names from it.
+     * NULL = off.  The growing stops at exactly those counts to copy the flow out, so the result is unchanged. */
+    void (*partial_cb)(void *user, int pair, int percent, int iteration, int part_idx, int w, int h, const float *flow);
+    void *partial_user;
 } faldoi_local_params;
 typedef struct faldoi_local_stats {
     long long pops[2];    /* candidates popped, forward / backward (summed over the batch) */

@@ -269,10 +269,34 @@ static const Direction *g_trace_dir = NULL;
 extern "C" void orc_trace_windows(int *buf, long cap) { g_trace = buf; g_trace_cap = cap; g_trace_len = 0; g_trace_dir = NULL; }
 extern "C" long orc_trace_length(void) { return g_trace_len; }
 
-// local_growing, src/local_faldoi.cpp:891-1039 (without the partial-result dumps)
-void local_growing(Direction &d, int iteration)
+// -partial_res 1 (src/local_faldoi.cpp:942-1036): the forward growings' flow at the reference's moments, kept in memory instead of
+// "../Results/Partial_results/*.flo" (orc_partial_enable / _count / _get); the test `percent > P[k] && percent < P[k+1]` and the
+// float percentage are the reference's, statement for statement.
+struct PartialDump { int percent, iteration, part_idx, w, h; std::vector<float> flow; };
+static bool g_partial_on = false;
+static std::vector<PartialDump> g_partial;
+static void partial_keep(const Direction &d, int percent, int iteration, int part_idx)
+{
+    PartialDump p{ percent, iteration, part_idx, d.w, d.h, std::vector<float>(d.out.begin(), d.out.begin() + 2 * (size_t)d.w * d.h) };
+#pragma omp critical(orc_partial)
+    g_partial.push_back(std::move(p));
+}
+extern "C" void orc_partial_enable(int on) { g_partial_on = on != 0; g_partial.clear(); }
+extern "C" int orc_partial_count(void) { return (int)g_partial.size(); }
+extern "C" void orc_partial_get(int k, int *meta /* percent, iteration, part_idx, w, h */, float *flow /* may be NULL */)
+{
+    const PartialDump &p = g_partial[(size_t)k];
+    meta[0] = p.percent; meta[1] = p.iteration; meta[2] = p.part_idx; meta[3] = p.w; meta[4] = p.h;
+    if (flow) memcpy(flow, p.flow.data(), sizeof(float) * p.flow.size());
+}
+
+// local_growing, src/local_faldoi.cpp:891-1039
+void local_growing(Direction &d, int iteration, bool fwd = false, int part_idx = -1)
 {
     const int w = d.w, n = d.w * d.h;
+    int percent_print[5] = { 30, 70, 80, 95, 100 };                       // :896
+    int fixed = 0;
+    const int size = n;
     while (!d.queue.empty()) {
         const Candidate c = d.queue.top();
         d.queue.pop();
@@ -289,9 +313,20 @@ void local_growing(Direction &d, int iteration)
             if (g_trace_len + 3 <= g_trace_cap) { g_trace[g_trace_len] = c.i; g_trace[g_trace_len + 1] = c.j; g_trace[g_trace_len + 2] = iteration; }
             g_trace_len += 3;
         }
+        fixed++;                                                          // :925
         add_neighbors(d, c.i, c.j, iteration, d.wr);
         spec_assign(d, iteration);
+        if (g_partial_on) {                                               // :942-994
+            float percent = 100 * fixed * 1.0 / size * 1.0;
+            for (int k = 0; k < 4; k++)
+                if (percent > percent_print[k] && percent < percent_print[k + 1])
+                    if (fwd) {
+                        partial_keep(d, percent_print[k], iteration, part_idx);
+                        percent_print[k] = 200;
+                    }
+        }
     }
+    if (g_partial_on && fwd) partial_keep(d, 100, iteration, part_idx);    // :996-1035
 }
 
 // fb_consistency_check, src/local_faldoi.cpp:167-190: |u(x) + v(x + u(x))| <= epsilon
@@ -612,12 +647,12 @@ extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const
     auto grow_partitions = [&](std::vector<Partition> &P, int it, int ndir) {
         const int count = (int)P.size() * ndir;
 #pragma omp parallel for schedule(dynamic)
-        for (int q = 0; q < count; q++) local_growing(P[q / ndir].d[q % ndir], it);
+        for (int q = 0; q < count; q++) local_growing(P[q / ndir].d[q % ndir], it, q % ndir == 0, q / ndir);
     };
     for (int it = 0; it < loc_it; it++) {                                          // :1184-1640
         if (!split_img || (it == 0 && split_img != 2)) {
 #pragma omp parallel for num_threads(2)
-            for (int k = 0; k < 2; k++) local_growing(d[k], it);
+            for (int k = 0; k < 2; k++) local_growing(d[k], it, k == 0, -1);
         } else {
             std::vector<Partition> &P = (it == 0 && !PC.empty()) ? PC : (it % 2 != 0) ? PA : PB;
             image_to_partitions(P, d, true);
@@ -626,7 +661,7 @@ extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const
                 image_to_partitions(P, d, false);
             } else {                                                               // :1349-1370: whole image instead
 #pragma omp parallel for num_threads(2)
-                for (int k = 0; k < 2; k++) local_growing(d[k], it);
+                for (int k = 0; k < 2; k++) local_growing(d[k], it, k == 0, -1);
             }
         }
         prune_and_reseed(d, w, h, fb_thresh);
@@ -637,10 +672,10 @@ extern "C" void orc_local_faldoi_split(const float *i0n, const float *i1n, const
             grow_partitions(PA, loc_it, 1);
             image_to_partitions(PA, d, false);
         } else {
-            local_growing(d[0], loc_it);
+            local_growing(d[0], loc_it, true, loc_it);                             // :1681 (part_idx = iter, sic)
         }
     } else {
-        local_growing(d[0], loc_it);                                               // :1703
+        local_growing(d[0], loc_it, true, loc_it);                                 // :1703
     }
     memcpy(out_flow, d[0].out.data(), sizeof(float) * 2 * n);
     memcpy(ene_val, d[0].ene.data(), sizeof(float) * n);
@@ -686,10 +721,10 @@ extern "C" void orc_local_faldoi_raw(const float *i0, const float *i1, int pd, c
     for (int k = 0; k < 2; k++) insert_initial_seeds(d[k], k == 0 ? go : ba);
     for (int it = 0; it < loc_it; it++) {
 #pragma omp parallel for num_threads(2)
-        for (int k = 0; k < 2; k++) local_growing(d[k], it);
+        for (int k = 0; k < 2; k++) local_growing(d[k], it, k == 0, -1);
         prune_and_reseed(d, w, h, fb_thresh);
     }
-    local_growing(d[0], loc_it);
+    local_growing(d[0], loc_it, true, loc_it);
     memcpy(out_flow, d[0].out.data(), sizeof(float) * 2 * n);
     memcpy(ene_val, d[0].ene.data(), sizeof(float) * n);
     if (stats)

@@ -106,6 +106,11 @@ def lib():
         L.orc_local_tvl1w_estimate.restype = C.c_float
         L.orc_local_faldoi.argtypes = [_F, _F, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float, C.c_int, _F, _F,
                                        np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
+        L.orc_partial_enable.argtypes = [C.c_int]
+        L.orc_partial_enable.restype = None
+        L.orc_partial_count.restype = C.c_int
+        L.orc_partial_get.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_partial_get.restype = None
         L.orc_local_faldoi_split.argtypes = [_F, _F, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float] + [C.c_int] * 6 + [
             _F, _F, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
         L.orc_local_faldoi_raw.argtypes = [_F, _F, C.c_int, _F, _F, _FN, _FN] + [C.c_int] * 5 + [C.c_float, C.c_int, _F, _F,
@@ -462,17 +467,30 @@ def preprocess_local(i0, i1):
 
 
 def local_faldoi(i0n, i1n, go, ba, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2.0, sal0=None, sal1=None, method=0,
-                 split_img=0, h_parts=3, v_parts=2, first_h_parts=0, first_v_parts=0):
+                 split_img=0, h_parts=3, v_parts=2, first_h_parts=0, first_v_parts=0, partial_res=False):
     """match_growing_variational (-m 0, no partitions).  go/ba: (2,h,w) seed flows, NaN = no seed.
-    Returns (out_flow (2,h,w), ene_val (h,w), stats[6])."""
+    Returns (out_flow (2,h,w), ene_val (h,w), stats[6]); with partial_res=True a fourth value: what -partial_res 1 writes
+    (src/local_faldoi.cpp:942-1036), as a dict {(percent, iteration, part_idx): flow (2,h',w')}."""
     i0n, i1n, go, ba = f32(i0n), f32(i1n), f32(go), f32(ba)
     h, w = i0n.shape
     out, ene, st = np.empty((2, h, w), np.float32), np.empty((h, w), np.float32), np.zeros(6, np.int64)
     keep = [f32(s) if s is not None else None for s in (sal0, sal1)]
     ptr = [k.ctypes.data if k is not None else None for k in keep]
-    lib().orc_local_faldoi_split(i0n, i1n, go, ba, ptr[0], ptr[1], w, h, wr, loc_it, max_iter_patch, fb_thresh, method,
-                                 split_img, h_parts, v_parts, first_h_parts, first_v_parts, out, ene, st)
-    return out, ene, st
+    L = lib()
+    L.orc_partial_enable(1 if partial_res else 0)
+    L.orc_local_faldoi_split(i0n, i1n, go, ba, ptr[0], ptr[1], w, h, wr, loc_it, max_iter_patch, fb_thresh, method,
+                             split_img, h_parts, v_parts, first_h_parts, first_v_parts, out, ene, st)
+    if not partial_res:
+        return out, ene, st
+    dumps = {}
+    for k in range(L.orc_partial_count()):
+        meta = np.zeros(5, np.int32)
+        L.orc_partial_get(k, meta.ctypes.data_as(C.c_void_p), None)
+        flow = np.empty((2, int(meta[4]), int(meta[3])), np.float32)
+        L.orc_partial_get(k, meta.ctypes.data_as(C.c_void_p), flow.ctypes.data_as(C.c_void_p))
+        dumps[(int(meta[0]), int(meta[1]), int(meta[2]))] = flow
+    L.orc_partial_enable(0)
+    return out, ene, st, dumps
 
 
 def local_faldoi_raw(i0, i1, go, ba, method, wr=5, loc_it=3, max_iter_patch=4, fb_thresh=2.0):

@@ -133,3 +133,64 @@ def test_fused_nltv_kernel_range_checked_build_is_clean(ctx):
     assert r2.returncode == 0, r2.stderr[-3000:]
     rep2 = json.loads(r2.stdout.strip().splitlines()[-1])
     assert not rep2["compiled_in"] and rep2["bits"] == 0 and rep2["sha256"] == rep["sha256"], (rep, rep2)
+
+
+# ------------------------------------------------------------------ -partial_res (src/local_faldoi.cpp:942-1036)
+def _partial_case(oracle, w, h, x0, y0, seed):
+    c0, c1 = sintel_pair((x0, y0, w, h))
+    a, b = oracle.preprocess_local(c0, c1)
+    rng = np.random.default_rng(seed)
+    go = np.full((2, h, w), np.nan, np.float32)
+    ba = np.full((2, h, w), np.nan, np.float32)
+    m = rng.random((h, w)) < 0.02
+    go[:, m] = np.round(rng.normal(0, 1.5, (2, int(m.sum())))).astype(np.float32)
+    m = rng.random((h, w)) < 0.02
+    ba[:, m] = np.round(rng.normal(0, 1.5, (2, int(m.sum())))).astype(np.float32)
+    return a, b, go, ba
+
+
+def test_partial_results_of_the_forward_growings_match_the_cpu_path(ctx, oracle, tmp_path):
+    """-partial_res 1: every forward growing hands out its flow the first time the share of pixels it has fixed passes 30 / 70 / 80 /
+    95 % (the reference's float test, so thresholds can be skipped on small domains) and when its queue is empty.  The device
+    growing stops at exactly those window counts (the launch budget is cut to land on them) -- the same set of dumps, bit for bit
+    (NaN where nothing is fixed yet), as the CPU restatement of local_growing; the final flow is unchanged by the stops.  Whole
+    image and the reference's partition mode; then the executable writes the reference's file names."""
+    import subprocess
+    for (w, h, x0, y0, split, budget) in ((96, 64, 300, 100, 0, 16384), (96, 64, 300, 100, 0, 700), (120, 80, 500, 200, 1, 16384),
+                                         (13, 9, 40, 40, 0, 5)):
+        a, b, go, ba = _partial_case(oracle, w, h, x0, y0, 5 + w)
+        kw = dict(split_img=split, h_parts=3, v_parts=2) if split else {}
+        want_flow, want_ene, _, want = oracle.local_faldoi(a, b, go, ba, partial_res=True, **kw)
+        got = {}
+        flow, ene, _ = ctx.match_growing(a, b, go, ba, preprocessed=1, budget=budget, partial_res=got, **kw)
+        plain, _, _ = ctx.match_growing(a, b, go, ba, preprocessed=1, **kw)
+        assert bits_equal(flow, want_flow) and bits_equal(ene, want_ene) and bits_equal(flow, plain)
+        got = {k[1:]: v for k, v in got.items()}                     # one pair: drop the pair index
+        assert sorted(got) == sorted(want), (w, h, split, sorted(got), sorted(want))
+        assert any(k[0] == 100 for k in got) and any(k[0] < 100 for k in got)
+        for k in want:
+            assert bits_equal(got[k], want[k]), (w, h, split, k, mismatch_report(got[k], want[k]))
+        if split:
+            assert any(k[2] >= 0 and k[1] > 0 for k in got) and any(k[2] == -1 for k in got)
+    # the executable: the reference's names under -partial_dir (additive; default ../Results/Partial_results/)
+    from PIL import Image
+    w, h, x0, y0 = 96, 64, 300, 100
+    c0, c1 = sintel_pair((x0, y0, w, h))
+    a, b, go, ba = _partial_case(oracle, w, h, x0, y0, 5 + w)
+    for k, im in enumerate((c0, c1)):
+        Image.fromarray(im.transpose(1, 2, 0).astype(np.uint8), "RGB").save(tmp_path / ("f%d.png" % k))
+    (tmp_path / "ims.txt").write_text("%s\n%s\n" % (tmp_path / "f0.png", tmp_path / "f1.png"))
+    for name, f in (("go.flo", go), ("ba.flo", ba)):
+        (tmp_path / name).write_bytes(F.flo.flo_bytes(f))
+    (tmp_path / "part").mkdir()
+    exe = F.build.build_host()["local_faldoi"]
+    r = subprocess.run([exe, str(tmp_path / "ims.txt"), str(tmp_path / "go.flo"), str(tmp_path / "ba.flo"), str(tmp_path / "out.flo"),
+                        str(tmp_path / "sim.tiff"), "-partial_res", "1", "-partial_dir", str(tmp_path / "part")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a2, b2 = oracle.preprocess_local(c0, c1)
+    _, _, _, want = oracle.local_faldoi(a2, b2, go, ba, partial_res=True)
+    names = sorted(p.name for p in (tmp_path / "part").iterdir())
+    assert names == sorted("partial_results_fwd_%d_iter_%d.flo" % (pc, it) for (pc, it, _) in want), names
+    for (pc, it, _), flow in want.items():
+        assert (tmp_path / "part" / ("partial_results_fwd_%d_iter_%d.flo" % (pc, it))).read_bytes() == F.flo.flo_bytes(flow)
