@@ -55,6 +55,19 @@ static int fail(int code, const char *fmt, ...)
 // ------------------------------------------------------------------------------------------ ABI hygiene
 namespace {
 // Host containers may throw; nothing crosses the C ABI.
+// Development hooks.  Everything the library reads from the environment that is NOT product behaviour -- tuning aids (FALDOI_TILE,
+// FALDOI_PERSIST_CFG, FALDOI_NL_ROWS, FALDOI_HEAP_TOP_LEVELS, FALDOI_WARP_LDS, FALDOI_WARP_WPS, FALDOI_SYNC_GROUP), measurement aids
+// (FALDOI_STAMPS, FALDOI_EVENT_TIMING, FALDOI_CHUNK_REPEAT, FALDOI_WARP_REPEAT: bench.py times kernels with the last two), and test
+// hooks that force a rare path (FALDOI_PERSIST_SPINS, FALDOI_GROW_DENSE, FALDOI_RESEED, FALDOI_TVCSAD_SERIAL_SUM, FALDOI_CSAD_SORT,
+// FALDOI_NL_CHECK_SELFTEST, FALDOI_SELFTEST_DUMP) -- goes through dev_env(), and ONE compile-time switch removes them all:
+// -DFALDOI_DEV_HOOKS=0 builds a library that reads only the three documented switches (FALDOI_PERSIST, FALDOI_EXACT_QUOTIENTS,
+// FALDOI_NL_FUSED).  The default build keeps the hooks: the suites and bench.py use them.  (The timing-only what-if
+// variants of the kernels are compile-time already: FALDOI_WHATIF, FALDOI_NFWHATIF, never defined in a product build.)
+#ifndef FALDOI_DEV_HOOKS
+#define FALDOI_DEV_HOOKS 1
+#endif
+static inline const char *dev_env(const char *name) { return FALDOI_DEV_HOOKS ? getenv(name) : nullptr; }
+
 template <typename Fn> int abi_guard(const char *what, Fn fn)
 {
     try {
@@ -361,7 +374,7 @@ static void pick_schedule(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *
     const bool small_job = tiles_big <= b->ctx->n_cu;
     *tc = small_job ? TileCfg{4, 16} : TileCfg{3, 12};
     int k = prm->chunk ? prm->chunk : (small_job ? 10 : 5);
-    if (const char *s = getenv("FALDOI_TILE")) {
+    if (const char *s = dev_env("FALDOI_TILE")) {
         int r = 0, w = 0;
         if (sscanf(s, "%d,%d", &r, &w) == 2 && tile_supported(r, w)) *tc = TileCfg{r, w};
     }
@@ -407,7 +420,7 @@ static void launch_warp(int variant, dim3 grid, hipStream_t s, float *base, size
 {
     // FALDOI_WARP_LDS=bytes (tuning aid): unused dynamic LDS per workgroup, which caps how many workgroups a CU keeps resident
     // (the kernel's waves all gather, then all compute; fewer resident waves stagger the two phases)
-    static const int lds = [] { const char *v = getenv("FALDOI_WARP_LDS"); const int b = v ? atoi(v) : 0; return b > 0 && b <= 65536 ? b : 0; }();
+    static const int lds = [] { const char *v = dev_env("FALDOI_WARP_LDS"); const int b = v ? atoi(v) : 0; return b > 0 && b <= 65536 ? b : 0; }();
     if (variant == 8)
         hipLaunchKernelGGL(tvl1_warp_kernel<8>, grid, dim3(256), lds, s, base, pe, nx, ny, npairs, ctl, st, cur);
     else if (variant == 6)
@@ -448,7 +461,7 @@ static bool pick_persist(const faldoi_tvl1_batch *b, const faldoi_tvl1_params *p
     if (b->persist_off) return false;                                     // a launch for this batch was refused by the runtime
     if (b->npairs != 1) return false;
     const bool dynamic = prm->tol_stop != 0;                              // tvl1_persist_dyn_kernel.hpp: built for 64x48 tiles only
-    if (const char *s = getenv("FALDOI_PERSIST_CFG")) {                   // tuning aid: R,NW,k
+    if (const char *s = dev_env("FALDOI_PERSIST_CFG")) {                   // tuning aid: R,NW,k
         int r = 0, w = 0, k = 0;
         if (sscanf(s, "%d,%d,%d", &r, &w, &k) == 3 && persist_supported(r, w) && (!dynamic || (r == 3 && w == 16))) {
             if (k > prm->max_inner) k = prm->max_inner;
@@ -697,11 +710,11 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     const int npix = b->nx * b->ny;
     const dim3 wgrid(((npix + 255) / 256) * b->npairs);
     int wvariant = 4;                                  // waves/SIMD the per-warp kernel is compiled for
-    if (const char *v = getenv("FALDOI_WARP_WPS")) wvariant = atoi(v);
+    if (const char *v = dev_env("FALDOI_WARP_WPS")) wvariant = atoi(v);
     int chunk_repeat = 1;
-    if (const char *v = getenv("FALDOI_CHUNK_REPEAT")) { const int r = atoi(v); if (r >= 1 && r <= 8) chunk_repeat = r; }
+    if (const char *v = dev_env("FALDOI_CHUNK_REPEAT")) { const int r = atoi(v); if (r >= 1 && r <= 8) chunk_repeat = r; }
     int warp_repeat = 1;
-    if (const char *v = getenv("FALDOI_WARP_REPEAT")) { const int r = atoi(v); if (r >= 1 && r <= 8) warp_repeat = r; }
+    if (const char *v = dev_env("FALDOI_WARP_REPEAT")) { const int r = atoi(v); if (r >= 1 && r <= 8) warp_repeat = r; }
     int launches = 0;
     HIP_TRY(hipEventRecord(c->ev0, s));
     HIP_TRY(hipMemsetAsync(b->d_done, 0, sizeof(int), s));
@@ -720,7 +733,7 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     // Optional per-launch timing of the fused kernel: one HIP event pair around every launch on the
     // context's stream (FALDOI_EVENT_TIMING=1; static schedule only).  Off by default: the events
     // add a little stream traffic, so the headline wall-clock is taken without them.
-    const bool ev_timing = !dynamic && getenv("FALDOI_EVENT_TIMING") && atoi(getenv("FALDOI_EVENT_TIMING")) > 0;
+    const bool ev_timing = !dynamic && dev_env("FALDOI_EVENT_TIMING") && atoi(dev_env("FALDOI_EVENT_TIMING")) > 0;
     size_t ev_used = 0;
     if (ev_timing) {
         const size_t need = 2 * (size_t)warps * ((prm->max_inner + chunk - 1) / chunk);
@@ -734,7 +747,7 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
     // its loads had landed, when its iterations ended and when its stores had drained (constant 100 MHz clock)
     unsigned long long *d_stamps = nullptr;
     DevBuf stamp_buf;
-    if (!dynamic && !persist && getenv("FALDOI_STAMPS") && atoi(getenv("FALDOI_STAMPS")) > 0) {
+    if (!dynamic && !persist && dev_env("FALDOI_STAMPS") && atoi(dev_env("FALDOI_STAMPS")) > 0) {
         HIP_TRY(hipMalloc((void **)&stamp_buf.p, sizeof(unsigned long long) * 4 * grid.x));
         d_stamps = reinterpret_cast<unsigned long long *>(stamp_buf.p);
         HIP_TRY(hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * 4 * grid.x, s));
@@ -751,7 +764,7 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(b->xflags, 0, flag_bytes, s));      // epochs count from 0 in every launch
         unsigned long long *p_stamps = nullptr;
-        if (getenv("FALDOI_STAMPS") && atoi(getenv("FALDOI_STAMPS")) > 0) {
+        if (dev_env("FALDOI_STAMPS") && atoi(dev_env("FALDOI_STAMPS")) > 0) {
             HIP_TRY(hipMalloc((void **)&stamp_buf.p, sizeof(unsigned long long) * kPersistStamps * ntiles));
             p_stamps = reinterpret_cast<unsigned long long *>(stamp_buf.p);
             HIP_TRY(hipMemsetAsync(p_stamps, 0, sizeof(unsigned long long) * kPersistStamps * ntiles, s));
@@ -770,7 +783,7 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         // long a wait means a workgroup that is not resident, not a slow one.  FALDOI_PERSIST_SPINS=0 (test hook): every tile gives
         // up at its first exchange, before it polls
         a.spin_limit = 40000u;
-        if (const char *v = getenv("FALDOI_PERSIST_SPINS")) { const long q = atol(v); if (q >= 0 && q < (1L << 31)) a.spin_limit = (unsigned)q; }
+        if (const char *v = dev_env("FALDOI_PERSIST_SPINS")) { const long q = atol(v); if (q >= 0 && q < (1L << 31)) a.spin_limit = (unsigned)q; }
         a.stamps = p_stamps;
         a.stamp_warp = warps / 2;
         a.unsafe = &b->ctl[0].unsafe;
@@ -836,7 +849,7 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         for (int i = 0; i < b->npairs; ++i) b->final_cur[i] = cur;
     } else {
         int group = 8;
-        if (const char *g = getenv("FALDOI_SYNC_GROUP")) { int v = atoi(g); if (v >= 1 && v <= 1024) group = v; }
+        if (const char *g = dev_env("FALDOI_SYNC_GROUP")) { int v = atoi(g); if (v >= 1 && v <= 1024) group = v; }
         const long max_launches = 2L * warps * ((prm->max_inner + chunk - 1) / chunk + 1) + group;
         for (;;) {
             for (int g = 0; g < group; ++g) {
@@ -891,7 +904,8 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         // before it tries again.  Counted in faldoi_ctx_persist_stats; said on stderr every time (the back-off bounds how often).
         ++c->persist_fallbacks;
         c->persist_backoff_len = c->persist_backoff_len ? (c->persist_backoff_len < 1024 ? 2 * c->persist_backoff_len : 1024) : 16;
-        c->persist_backoff = c->persist_backoff_len + 1;           // + the redo below
+        c->persist_backoff = c->persist_backoff_len + 1;           // + the redo below ...
+        --c->persist_backed_off;                                   // ... which is this same solve, not one more that was kept off the path
         fprintf(stderr, "faldoi: the persistent TV-L1 kernel gave up waiting for a neighbouring tile (first at tile %d): its workgroups "
                         "were not all resident; using the per-launch path for this and the next %d solves of this context (give-up %ld)\n",
                 *c->h_done - 1, c->persist_backoff_len, c->persist_fallbacks);
@@ -1150,7 +1164,10 @@ static int faldoi_zoom_out_impl(faldoi_ctx *ctx, const float *I, float *Iout, in
 
 extern "C" int faldoi_zoom_out(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, float factor)
 {
-    return abi_guard("zoom_out", [&] { return faldoi_zoom_out_impl(ctx, I, Iout, nx, ny, factor); });
+    return abi_guard("zoom_out", [&] {
+        OpScope scope(ctx);                       // (kernels of this call count as work on the device: DeviceGate)
+        return faldoi_zoom_out_impl(ctx, I, Iout, nx, ny, factor);
+    });
 }
 
 static int faldoi_zoom_in_impl(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
@@ -1165,7 +1182,10 @@ static int faldoi_zoom_in_impl(faldoi_ctx *ctx, const float *I, float *Iout, int
 
 extern "C" int faldoi_zoom_in(faldoi_ctx *ctx, const float *I, float *Iout, int nx, int ny, int nxx, int nyy)
 {
-    return abi_guard("zoom_in", [&] { return faldoi_zoom_in_impl(ctx, I, Iout, nx, ny, nxx, nyy); });
+    return abi_guard("zoom_in", [&] {
+        OpScope scope(ctx);                       // (kernels of this call count as work on the device: DeviceGate)
+        return faldoi_zoom_in_impl(ctx, I, Iout, nx, ny, nxx, nyy);
+    });
 }
 
 // Device-side pipeline on three gray planes already in HBM (A = i0, B = i1, C = i_1), in place.
@@ -1246,7 +1266,10 @@ static int faldoi_preprocess_global_impl(faldoi_ctx *ctx, const float *i0, const
 extern "C" int faldoi_preprocess_global(faldoi_ctx *ctx, const float *i0, const float *i1, const float *im1, int nx,
                                         int ny, int pd, float *i0n, float *i1n)
 {
-    return abi_guard("the preprocessing", [&] { return faldoi_preprocess_global_impl(ctx, i0, i1, im1, nx, ny, pd, i0n, i1n); });
+    return abi_guard("the preprocessing", [&] {
+        OpScope scope(ctx);                       // (kernels of this call count as work on the device: DeviceGate)
+        return faldoi_preprocess_global_impl(ctx, i0, i1, im1, nx, ny, pd, i0n, i1n);
+    });
 }
 
 static int faldoi_tvl1_batch_upload_images_impl(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
@@ -1291,7 +1314,10 @@ static int faldoi_tvl1_batch_upload_images_impl(faldoi_tvl1_batch *b, int pair, 
 extern "C" int faldoi_tvl1_batch_upload_images(faldoi_tvl1_batch *b, int pair, const float *i0, const float *i1,
                                                const float *im1, int pd, const float *u, const float *xi)
 {
-    return abi_guard("the batch upload", [&] { return faldoi_tvl1_batch_upload_images_impl(b, pair, i0, i1, im1, pd, u, xi); });
+    return abi_guard("the batch upload", [&] {
+        OpScope scope(b ? b->ctx : nullptr);                       // (kernels of this call count as work on the device: DeviceGate)
+        return faldoi_tvl1_batch_upload_images_impl(b, pair, i0, i1, im1, pd, u, xi);
+    });
 }
 
 // ------------------------------------------------------------------------------------------ NLTV-CSAD
@@ -1485,7 +1511,7 @@ extern "C" int faldoi_debug_nl_check(faldoi_ctx *ctx, unsigned out[4], int reset
 
 static bool csad_sort_requested()
 {
-    const char *v = getenv("FALDOI_CSAD_SORT");
+    const char *v = dev_env("FALDOI_CSAD_SORT");
     return v && atoi(v) > 0;
 }
 
@@ -1541,12 +1567,15 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
     int ty = 0;
     if (fused) {
         ty = nl_pick_rows(nx, ny, ctx->n_cu);
-        if (const char *v = getenv("FALDOI_NL_ROWS")) { const int q = atoi(v); if (q == 8 || q == 12 || q == 14 || q == 16) ty = q; }   // tuning aid
+        if (const char *v = dev_env("FALDOI_NL_ROWS")) { const int q = atoi(v); if (q == 8 || q == 12 || q == 14 || q == 16) ty = q; }   // tuning aid
         fa.base = base; fa.pe = pe; fa.nx = nx; fa.ny = ny;
         fa.ntx = (nx + kNfW - 1) / kNfW; fa.nty = (ny + ty - 1) / ty;
         fa.cur = 0; fa.tau = prm->tau; fa.l_t = l_t; fa.theta = prm->theta; fa.rtheta = 1.0 / (double)prm->theta;
-        fa.check_selftest = (getenv("FALDOI_NL_CHECK_SELFTEST") && atoi(getenv("FALDOI_NL_CHECK_SELFTEST")) > 0) ? 1 : 0;
-        HIP_TRY(nl_fused_prepare(data_l1, ty));
+        fa.check_selftest = (dev_env("FALDOI_NL_CHECK_SELFTEST") && atoi(dev_env("FALDOI_NL_CHECK_SELFTEST")) > 0) ? 1 : 0;
+        if (nl_fused_prepare(data_l1, ty) != hipSuccess) {              // (less LDS than the kernel asks for: the streaming kernels instead)
+            (void)hipGetLastError();
+            fused = false;
+        }
     }
     HIP_TRY(hipEventRecord(ctx->ev0, s));
     hipLaunchKernelGGL(centered_gradient_kernel, grid, block, 0, s, base + N_I1 * pe, base + N_I1X * pe, base + N_I1Y * pe,
@@ -1558,9 +1587,17 @@ static int nl_solve(bool data_l1, faldoi_ctx *ctx, const float *I0, const float 
                                reinterpret_cast<unsigned *>(base + N_RK * pe), pe, nx, ny);
         for (int it = 0; it < prm->max_inner; ++it) {                           // :1729 / :1240, no tolerance test
             if (fused) {
-                HIP_TRY(nl_fused_launch(data_l1, ty, s, fa));
-                fa.cur ^= 1;                                                    // duals and ubar: read one buffer, write the other
-                continue;
+                const hipError_t e = nl_fused_launch(data_l1, ty, s, fa);
+                if (e == hipSuccess) {
+                    fa.cur ^= 1;                                                // duals and ubar: read one buffer, write the other
+                    continue;
+                }
+                // a refused FIRST launch (nothing has been written yet; the per-warp kernel put ubar where both paths read it) sends
+                // the whole solve to the two streaming kernels, which return the same bits; anything later is an error
+                if (w != 0 || it != 0) HIP_TRY(e);
+                (void)hipGetLastError();
+                fprintf(stderr, "faldoi: the fused NLTV kernel could not be launched (%s); using the two-kernel path\n", hipGetErrorString(e));
+                fused = false;
             }
             hipLaunchKernelGGL(nl_dual_kernel, grid, block, 0, s, base, pe, nx, ny, prm->tau);
             if (data_l1)
@@ -1647,7 +1684,10 @@ static int faldoi_local_tvl1_create_impl(faldoi_ctx *ctx, const float *I0, const
 extern "C" int faldoi_local_tvl1_create(faldoi_ctx *ctx, const float *I0, const float *I1, int nx, int ny,
                                         faldoi_local_tvl1 **out)
 {
-    return abi_guard("the local operator", [&] { return faldoi_local_tvl1_create_impl(ctx, I0, I1, nx, ny, out); });
+    return abi_guard("the local operator", [&] {
+        OpScope scope(ctx);                       // (kernels of this call count as work on the device: DeviceGate)
+        return faldoi_local_tvl1_create_impl(ctx, I0, I1, nx, ny, out);
+    });
 }
 
 extern "C" int faldoi_local_tvl1_set_flow(faldoi_local_tvl1 *h, const float *u)
@@ -1762,7 +1802,7 @@ static int faldoi_selftest_division_impl(faldoi_ctx *ctx, unsigned seed, unsigne
     unsigned long long *d = nullptr;
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float *dump = nullptr;
-    const int dump_cap = getenv("FALDOI_SELFTEST_DUMP") ? 64 : 0;
+    const int dump_cap = dev_env("FALDOI_SELFTEST_DUMP") ? 64 : 0;
     if (dump_cap) HIP_TRY(hipMalloc((void **)&dump, sizeof(float) * 4 * dump_cap));
     HIP_TRY(hipMalloc((void **)&d, sizeof h));
     hipError_t e = hipMemsetAsync(d, 0, sizeof h, ctx->stream);
@@ -1797,7 +1837,10 @@ static int faldoi_selftest_division_impl(faldoi_ctx *ctx, unsigned seed, unsigne
 extern "C" int faldoi_selftest_division(faldoi_ctx *ctx, unsigned seed, unsigned long long count,
                                         unsigned long long *mismatches)
 {
-    return abi_guard("the division self-test", [&] { return faldoi_selftest_division_impl(ctx, seed, count, mismatches); });
+    return abi_guard("the division self-test", [&] {
+        OpScope scope(ctx);                       // (kernels of this call count as work on the device: DeviceGate)
+        return faldoi_selftest_division_impl(ctx, seed, count, mismatches);
+    });
 }
 
 // ------------------------------------------------------------------------------------------ primitives
@@ -1816,6 +1859,7 @@ static int run_planes(faldoi_ctx *ctx, int nx, int ny, const float *const *in, i
 {
     int rc = prim_check(ctx, nx, ny);
     if (rc) return rc;
+    OpScope scope(ctx);                                  // (the primitives' kernels count as work on the device too: DeviceGate)
     for (int i = 0; i < nin; ++i) if (!in[i]) return fail(FALDOI_ERR_INVALID, "NULL input plane");
     for (int i = 0; i < nout; ++i) if (!out[i]) return fail(FALDOI_ERR_INVALID, "NULL output plane");
     const size_t n = (size_t)nx * ny, nb = n * sizeof(float);

@@ -12,7 +12,7 @@
  *   - plain C types only; every function returns an int status (FALDOI_OK == 0) and never
  *     throws or aborts (the reference's void functions abort()/assert on failure);
  *   - a faldoi_ctx owns one device + one HIP stream + workspaces; distinct contexts may be used
- *     from distinct host threads at the same time, also on one device (tested: tests/test_gpu_parity.py,
+ *     from distinct host threads at the same time, also on one device (tested: tests/test_gpu_round3.py,
  *     "threads"); one context is not thread-safe (mirrors the reference's per-thread
  *     SpecificOFStuff/OpticalFlowData ownership, src/local_faldoi.cpp:1192-1219,1305-1347);
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point returns
