@@ -194,3 +194,28 @@ def test_partial_results_of_the_forward_growings_match_the_cpu_path(ctx, oracle,
     assert names == sorted("partial_results_fwd_%d_iter_%d.flo" % (pc, it) for (pc, it, _) in want), names
     for (pc, it, _), flow in want.items():
         assert (tmp_path / "part" / ("partial_results_fwd_%d_iter_%d.flo" % (pc, it))).read_bytes() == F.flo.flo_bytes(flow)
+
+
+def test_bench_per_rank_parity_path_rehearsed_on_one_gpu():
+    """BASELINE configs[3] is 8 ranks x 4 pairs; no 8-GPU node has been available to the driver, so the per-rank evidence a SCALE
+    line would carry (bench.py: per_rank_check -- a checksum of every rank's resident flow and a bounded bit comparison with the
+    CPU checker) is exercised here on the one GPU: `bench.py --pairs-per-gpu 4` with FALDOI_BENCH_RANK_CHECK=1, as a child."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FALDOI_BENCH_RANK_CHECK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "FALDOI_LIB"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--pairs-per-gpu", "4", "--steps", "2", "--warmup", "1",
+                        "--no-secondary"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["pairs_per_gpu"] == 4 and line["scaling"] == "weak"
+    assert line["config"]["kernel_path"] == "one launch per chunk of iterations"
+    chk = line["per_rank_check"]
+    assert len(chk) == 1 and chk[0]["rank"] == 0 and len(chk[0]["flow_sha256_48"]) == 12
+    assert chk[0]["bit_identical_to_cpu_first_30_warps"] is True
+    assert line["epe_vs_cpu"]["bit_identical"] is True and line["value"] > 50000
+    assert not line.get("secondary_errors"), line.get("secondary_errors")

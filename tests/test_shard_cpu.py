@@ -132,6 +132,28 @@ def test_bench_gpus_n_starts_n_ranks_itself(tmp_path):
     assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
 
 
+def test_bench_launcher_at_eight_ranks_configs3_shape():
+    """BASELINE configs[3] is 8 ranks x 4 pairs: the same launcher path at N = 8 (no 8-GPU node has been available to the driver,
+    so the rank plumbing of a future SCALE line is rehearsed here): one line, eight per-rank rates, SUM = 8 x steps x 4 units,
+    MAX = the slowest rank's time (rank r sleeps (r + 1) x 10 ms per step)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "0",
+                        "--pairs-per-gpu", "4", "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks"] == 8 and len(out["per_rank"]) == 8
+    assert out["units"] == 8 * 2 * 4
+    assert out["seconds_max"] >= 2 * 0.08 * 0.9
+    assert all(v > 0 for v in out["per_rank"])             # (barriers bracket the timed region: every rank's clock covers the slowest)
+
+
 def test_batch_load_jobs_rejects_mismatched_inputs(tmp_path):
     """load_jobs (rank 0 of batch.py) raises on unreadable or mismatched inputs; main() turns that into an error
     marker broadcast to every rank instead of leaving them in the collective."""
