@@ -774,6 +774,13 @@ static int faldoi_tvl1_batch_solve_impl(faldoi_tvl1_batch *b, const faldoi_tvl1_
         a.plane_elems = b->plane_elems;
         a.nx = b->nx; a.ny = b->ny; a.ntx = ntx; a.nty = nty;
         a.hx = chunk; a.hy = pc.hy;
+        // the rows the grid has to spare go half to the first tile row, half to the last (PersistArgs::yshift); FALDOI_PERSIST_YSHIFT=0
+        // (development hook) keeps the grid flush with the image's first row, as in rounds 2 and 3
+        a.yshift = (((nty * Sy - b->ny) / 2) / pc.R) * pc.R;
+        if (const char *v = dev_env("FALDOI_PERSIST_YSHIFT")) {
+            const int q = atoi(v);
+            if (q >= 0 && q % pc.R == 0 && q <= nty * Sy - b->ny) a.yshift = q;
+        }
         a.prm = k;
         a.err_out = b->err_part;
         a.xslab = b->xslab;

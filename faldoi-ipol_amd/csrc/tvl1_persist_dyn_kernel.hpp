@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void tvl1_persist_dyn_kernel(PersistArgs a
     const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (t >= a.ntx * a.nty) return;
     const int tyi = t / a.ntx, txi = t - tyi * a.ntx;
-    const int X0 = txi * (kTileW - 2 * a.hx) - a.hx, Y0 = tyi * (TH - 2 * a.hy) - a.hy;
+    const int X0 = txi * (kTileW - 2 * a.hx) - a.hx, Y0 = tyi * (TH - 2 * a.hy) - a.hy - a.yshift;
     const bool colb = X0 <= 0 || X0 + kTileW >= a.nx, rowb = Y0 <= 0 || Y0 + TH >= a.ny;
 #define FALDOI_BODY(B) tvl1_persist_dyn_body<R, NW, B, ONCE>(a, t, txi, tyi, s_ub1, s_ub2, s_x12, s_x22, s_err, s_ctl, s_dec, s_snap)
     if (colb && rowb) FALDOI_BODY(3);

@@ -49,6 +49,11 @@ struct PersistArgs {
     size_t plane_elems;
     int nx, ny, ntx, nty;
     int hx, hy;                    // halo columns (= iterations per chunk) and halo rows (multiple of R, >= hx)
+    int yshift;                    // the tile grid starts this many rows ABOVE the image (a multiple of R): tile row j owns image rows
+                                   // [j Sy - yshift, (j+1) Sy - yshift).  The rows a grid has to spare (nty Sy - ny) are split between the
+                                   // first and the last tile row instead of all going to the last: both then hold about half a tile of
+                                   // image rows, and the tiles that run the row / corner variants of the iteration (the slowest
+                                   // instruction streams, profiles/r04_frame_tiles.md) stop pacing their neighbours
     TvConst prm;                   // prm.chunk = iterations per exchange
     float *err_out;                // [warps][ntiles][kMaxChunk]
     float *xslab;                  // [2][ntiles][kXPlanes][NW][64] x 16 B
@@ -101,24 +106,25 @@ __device__ __forceinline__ PxGeom px_geometry(const PersistArgs &a, int t, int t
     const int Sx = kTileW - 2 * a.hx, Sy = TH - 2 * a.hy;
     PxGeom g;
     g.gx = txi * Sx - a.hx + lane;
-    g.gy0 = tyi * Sy - a.hy + wv * R;                  // hy and Sy are multiples of R: a thread's rows share their owner
+    const int own_lo = tyi * Sy - a.yshift, own_hi = own_lo + Sy;            // image rows this tile owns (clipped by the image below)
+    g.gy0 = own_lo - a.hy + wv * R;                    // hy, Sy and yshift are multiples of R: a thread's rows share their owner
     g.col_in = g.gx >= 0 && g.gx < a.nx;
     const bool col_own = g.col_in && g.gx >= txi * Sx && g.gx < (txi + 1) * Sx;
     const bool group_in = g.gy0 >= 0 && g.gy0 < a.ny;
-    const bool group_own = group_in && g.gy0 >= tyi * Sy && g.gy0 < (tyi + 1) * Sy;
+    const bool group_own = group_in && g.gy0 >= own_lo && g.gy0 < own_hi;
     g.wave_live = group_in;
     g.owner = col_own && group_own;
     g.halo = g.col_in && group_in && !g.owner;
-    g.ring = g.owner && (g.gx - txi * Sx < a.hx || (txi + 1) * Sx - 1 - g.gx < a.hx || g.gy0 - tyi * Sy < a.hy ||
-                         (tyi + 1) * Sy - (g.gy0 + R) < a.hy);
+    g.ring = g.owner && (g.gx - txi * Sx < a.hx || (txi + 1) * Sx - 1 - g.gx < a.hx || g.gy0 - own_lo < a.hy ||
+                         own_hi - (g.gy0 + R) < a.hy);
     g.plane_stride = (unsigned)(NW * kTileW) * 16u;
     const unsigned tile_stride = g.plane_stride * (unsigned)kXPlanes;
     g.parity_stride = tile_stride * (unsigned)(a.ntx * a.nty);
     g.pub_off = (unsigned)t * tile_stride + (unsigned)(wv * kTileW + lane) * 16u;
     g.src_off = 0;
     if (g.halo) {
-        const int txp = g.gx / Sx, typ = g.gy0 / Sy;
-        const int lane_p = g.gx - txp * Sx + a.hx, wave_p = (g.gy0 - typ * Sy + a.hy) / R;
+        const int txp = g.gx / Sx, typ = (g.gy0 + a.yshift) / Sy;
+        const int lane_p = g.gx - txp * Sx + a.hx, wave_p = (g.gy0 + a.yshift - typ * Sy + a.hy) / R;
         g.src_off = (unsigned)(typ * a.ntx + txp) * tile_stride + (unsigned)(wave_p * kTileW + lane_p) * 16u;
     }
     return g;
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(64 * NW) void tvl1_persist_kernel(PersistArgs a)
     const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (t >= a.ntx * a.nty) return;
     const int tyi = t / a.ntx, txi = t - tyi * a.ntx;
-    const int X0 = txi * (kTileW - 2 * a.hx) - a.hx, Y0 = tyi * (TH - 2 * a.hy) - a.hy;
+    const int X0 = txi * (kTileW - 2 * a.hx) - a.hx, Y0 = tyi * (TH - 2 * a.hy) - a.hy - a.yshift;
     const bool colb = X0 <= 0 || X0 + kTileW >= a.nx, rowb = Y0 <= 0 || Y0 + TH >= a.ny;
 #define FALDOI_BODY(B) tvl1_persist_body<R, NW, B, ONCE>(a, t, txi, tyi, s_ub1, s_ub2, s_x12, s_x22, s_err, s_ctl)
     if (colb && rowb) FALDOI_BODY(3);
