@@ -54,6 +54,28 @@ struct GrowDir {                      // per growing: device pointers (array in 
     size_t pe;                        // plane stride of `planes`, `out`, `seed_flow`
     float *duals;                     // -m 2, 3, 6, 7: the non-local dual values p | q, [48][pe] (persistent across windows)
     const float *wp;                  // ... and the constant non-local weights, [24][pe]
+    int detail;                       // measurement aid (FALDOI_GROW_DETAIL=1): thread 0 of growing 0 splits its cycles by sub-phase
+};
+
+// FALDOI_GROW_DETAIL=1 (tests/tools/time_growing.py --detail): where the committing wavefront's cycles go, finer than GrowCtl's
+// three sums.  Thread 0 of the launch's first growing adds the shader-clock cycles since its previous mark to a device word
+// (fire-and-forget atomics).  Slots: 0 pop | 1 trust test + neighbour prefetch | 2 fill: window loaded | 3 fill: pyramid built |
+// 4 fill: level initialisation and hole masks | 5 fill: sweeps of level 0 | 6 fill: sweeps of the coarser levels | 7 fill: result
+// handed over | 8 solve: bicubic warp + set-up | 9 solve: iterations | 10 solve: flow stored + energy | 11 candidates pushed
+constexpr int kGrowDetailSlots = 12;
+__device__ unsigned long long g_grow_detail[kGrowDetailSlots];
+struct GrowStamp {
+    bool on;
+    long long last;
+    __device__ __forceinline__ void start() { if (on) last = clock64(); }
+    __device__ __forceinline__ void mark(int slot)
+    {
+        if (on) {
+            const long long now = clock64();
+            atomicAdd(&g_grow_detail[slot], (unsigned long long)(now - last));
+            last = now;
+        }
+    }
 };
 
 struct GrowShared {
@@ -97,7 +119,7 @@ __device__ __forceinline__ void wave_sync()
 }
 
 __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float *out, size_t pe, const int *fixed, int nx,
-                                                     int ii, int ij, int pw, int ph, float &u1, float &u2)
+                                                     int ii, int ij, int pw, int ph, float &u1, float &u2, GrowStamp &gs)
 {
     const int t = threadIdx.x, c = t >> 6, lane = t & 63;
     const int g = lane >> 4, i = lane & 15;
@@ -118,6 +140,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         in[q] = (fx == 1) ? val : __builtin_nanf("");
     }
     wave_sync();
+    gs.mark(2);
 #pragma unroll
     for (int s = 1; s < kElapLevels; ++s) {                         // zoom_out_by_factor_two :160-175
         const int iw = ws[s - 1], ih = hs[s - 1], ow = ws[s];
@@ -145,6 +168,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         }
         wave_sync();
     }
+    gs.mark(3);
     const float *coarse = fin;                                      // solution of the level below (level-relative indexing)
 #pragma unroll
     for (int s = kElapLevels - 1; s >= 0; --s) {
@@ -192,6 +216,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         // the column to the left (lane i-1 of the same 16-lane group); row_shr:1, zero at the row start
         const unsigned holes_left = (unsigned)__builtin_amdgcn_update_dpp(0, (int)holes, 0x111, 0xf, 0xf, true);
         wave_sync();
+        gs.mark(4);
         if (__builtin_amdgcn_ballot_w64(holes != 0u) == 0ull) {     // no hole at this level: the sweeps change nothing
             coarse = sm.ver[c][0] + o;
             continue;
@@ -253,6 +278,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         const float m1 = lane_read(mx, 15), m2 = lane_read(mx, 31);
         const int kfin = ((double)m1 < 1e-10) ? 1 : (((double)m2 < 1e-10) ? 2 : 3);     // :66-67
         coarse = sm.ver[c][kfin] + o;                               // the version the reference stops at
+        gs.mark(s == 0 ? 5 : 6);
     }
     if (lane == 0) sm.res[c] = (int)(coarse - sm.ver[c][0]);        // where this channel's level-0 solution lies
     __syncthreads();
@@ -262,6 +288,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         u1 = sm.ver[0][0][sm.res[0] + t];
         u2 = sm.ver[1][0][sm.res[1] + t];
     }
+    gs.mark(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -279,7 +306,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
 // during the call (src/energy_model.cpp:744-745), and the data energy is weighted (:227, a double product).
 __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_t pe, int nx, int ny, int ii, int ij, int ei,
                                               int ej, int max_iter_patch, float &u1, float &u2, const float *weight, int iiw,
-                                              int ijw, int wr_call, int shadow)
+                                              int ijw, int wr_call, int shadow, GrowStamp &gs)
 {
     const int pw = ei - ii, ph = ej - ij, t = threadIdx.x;
     const bool act = t < pw * ph;
@@ -339,6 +366,7 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
     sm.a[t] = ub1;
     sm.b[t] = ub2;
     __syncthreads();
+    gs.mark(8);
     int it = 0;
     float err_D = __builtin_inff();
     // The per-pixel steps are the ones of the global solver (faldoi_device.hpp): same expressions as
@@ -383,6 +411,7 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         err_D = e1 > e0 ? e1 : e0;
     }
     __syncthreads();                                     // every read of ubar is done before u overwrites it
+    gs.mark(9);
 
     // ---- eval_tvl2coupled (src/tvl2_model.cpp:174-243) ----
     sm.a[t] = u1;
@@ -451,6 +480,7 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         }
         ener = (float)((double)ener / (m * 1.0));
     }
+    gs.mark(10);
     return ener;
 }
 
@@ -580,7 +610,7 @@ __device__ __forceinline__ void heap_remove_top_wave(const HeapRef &h, int &size
 template <int FN>
 __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, const GrowDir &D, size_t pe, int nx, int ny, int i, int j,
                                                   int iteration, int wr, int max_iter_patch, const HeapRef &heap, int &heap_size,
-                                                  long long &fills, long long *cyc)
+                                                  long long &fills, long long *cyc, GrowStamp &gs)
 {
     const int t = threadIdx.x;
     const int ii = (i - wr < 0) ? 0 : i - wr, ij = (j - wr < 0) ? 0 : j - wr;             // get_index_patch
@@ -609,9 +639,10 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
         cene = D.ene[j * nx + i];
     }
     float u1 = 0.0f, u2 = 0.0f;
+    gs.mark(1);
     const long long c0 = clock64();
     if (fill) {
-        harmonic_fill_window(sm, D.out, pe, D.fixed, nx, ii, ij, pw, ph, u1, u2);
+        harmonic_fill_window(sm, D.out, pe, D.fixed, nx, ii, ij, pw, ph, u1, u2, gs);
         if (t == 0) ++fills;
     } else if (act) {
         u1 = D.planes[L_U1 * pe + p];
@@ -621,7 +652,7 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
     const int iiw = (i - wr < 0) ? -(i - wr) : 0, ijw = (j - wr < 0) ? -(j - wr) : 0;    // get_relative_index_weight :551-557
     float ener;
     if constexpr (FN == 0)
-        ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2, D.weight, iiw, ijw, wr, D.shadow);
+        ener = window_solve(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2, D.weight, iiw, ijw, wr, D.shadow, gs);
     else if constexpr (FN == 1)
         ener = window_solve_nl<true, kDataL1>(sm, *ns, D.planes, D.duals, D.wp, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch,
                                               u1, u2, D.weight, iiw, ijw, wr, D.method);
@@ -655,6 +686,7 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
             D.ene[g] = ener0;
         }
     }
+    gs.mark(11);
     if (t == 0) {
         cyc[0] += clock64() - c2;
         cyc[1] += c1 - c0;
@@ -684,6 +716,8 @@ __device__ __forceinline__ void grow_body(GrowShared &sm, NlShared *ns, const Gr
         seed_pos = D.ctl->seed_pos;
     }
     int done = 0;
+    GrowStamp gs{ D.detail != 0 && blockIdx.x == 0 && t == 0 && mode == 1, 0 };
+    gs.start();
     for (int step = 0; step < budget; ++step) {
         if (t < 64) {
             int have = 0, g = 0;
@@ -727,8 +761,9 @@ __device__ __forceinline__ void grow_body(GrowShared &sm, NlShared *ns, const Gr
         }
         __syncthreads();
         if (!sm.cur[0]) { done = 1; break; }
+        gs.mark(0);
         const int i = sm.cur[1], j = sm.cur[2];
-        add_neighbors_dev<FN>(sm, ns, D, pe, nx, ny, i, j, iteration, mode == 0 ? 1 : wr, max_iter_patch, heap, heap_size, fills, cyc);
+        add_neighbors_dev<FN>(sm, ns, D, pe, nx, ny, i, j, iteration, mode == 0 ? 1 : wr, max_iter_patch, heap, heap_size, fills, cyc, gs);
         if (t == 0) {
             ++solves;
             if (mode == 0) {                                                      // :778-780
