@@ -28,6 +28,8 @@ python3 tools/pmc_summary.py --out $OUT/counters.json --label "$TAG: python3 ben
     --grid tvl1_persist_kernel=253952 --grid tvl1_chunk_kernel=245760 --grid tvl1_warp_kernel=446464 --grid nl_fused_kernel=458752 \
     --grid tvl1_chunk_kernel@batch4=995328 --grid tvl1_warp_kernel@batch4=1785856 --tile tvl1_chunk_kernel@batch4=3,12,5,4,1024x436 \
     $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/fetch $OUT/write
-find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+# (the bench starts child processes -- the drop-in executable of its end_to_end leg -- and each writes its own summary: keep the bench's,
+# the largest one)
+cp "$(find $OUT/stats -name "*kernel_stats.csv" -printf '%s %p\n' | sort -n | tail -1 | cut -d' ' -f2-)" $OUT/kernel_stats.csv
 rm -rf $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/fetch $OUT/write
 echo done
