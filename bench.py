@@ -223,22 +223,32 @@ def main():
     npairs = args.pairs_per_gpu
     ctx = F.Context(local_rank)
     batch = F.Tvl1Batch(ctx, npairs, W, H)
-    # Pair 0 of rank 0 is the reference's own example pair (Sintel clean/easy frames 2->3, committed
-    # under tests/golden), prepared by the library's device-side preprocessing; every other pair
-    # (more pairs per GPU, other ranks) is a seeded synthetic pair of the same size.
+    # The job is the list SURVEY 8d gives for BASELINE configs[3]: the reference's 18 example frame pairs (six sequences x frames
+    # 1->2, 2->3, 3->4; committed under tests/golden, the headline's clean/easy 2->3 first) followed by seeded synthetic pairs of the
+    # same size, dealt round-robin -- global pair g goes to rank g % world (shard.assign_pairs), so rank r's i-th pair is g = r + i *
+    # world.  Real pairs are prepared by the library's device-side preprocessing.  One pair on one GPU is the headline's pair.
+    from util import reference_pairs
+    real = [p for p in reference_pairs() if os.path.exists(p[1]) and os.path.exists(p[2])]
     pairs = []
     f2 = os.path.join(GOLDEN, "sintel_clean_easy_frame_0002.png")
     f3 = os.path.join(GOLDEN, "sintel_clean_easy_frame_0003.png")
-    data_kind = "synthetic"
-    for i in range(npairs):
+    mine = F.shard.assign_pairs(npairs * world, world, rank)
+    names = []
+    for i, g in enumerate(mine):
         u0 = np.zeros((2, H, W), np.float32)
-        if rank == 0 and i == 0 and os.path.exists(f2) and os.path.exists(f3):
-            i0n, i1n = ctx.preprocess_global(load_rgb_planar(f2), load_rgb_planar(f3))
-            data_kind = "sintel clean/easy frames 2-3 (reference example_data, committed fixture), zero initial flow"
+        if g < len(real):
+            i0n, i1n = ctx.preprocess_global(load_rgb_planar(real[g][1]), load_rgb_planar(real[g][2]))
+            names.append("sintel " + real[g][0])
         else:
-            i0n, i1n, _ = synthetic_pair(W, H, seed=1234 + rank * npairs + i, amp=4.0)
+            i0n, i1n, _ = synthetic_pair(W, H, seed=1234 + g, amp=4.0)
+            names.append("synthetic seed %d" % (1234 + g))
         batch.upload(i, i0n, i1n, u0)
         pairs.append((i0n, i1n, u0))
+    n_real_total = min(len(real), npairs * world)
+    data_kind = "synthetic" if not real else (
+        "sintel clean/easy frames 2-3 (reference example_data, committed fixture), zero initial flow" if npairs * world == 1 else
+        "%d of the reference's 18 example frame pairs (committed fixtures) + %d seeded synthetic pairs, round-robin over the ranks, "
+        "zero initial flow" % (n_real_total, npairs * world - n_real_total))
     prm = dict(warps=WARPS, max_inner=INNER, tol_stop=0, chunk=args.chunk)
 
     def step():
@@ -364,7 +374,19 @@ def batch_leg(out, args, F, np, ctx, pairs, synthetic_pair, n4):
     pairs only) from the profile of this very command (tools/profile_bench.sh), used only while sources and durations still match."""
     b = F.Tvl1Batch(ctx, n4, W, H)
     try:
-        ps = [pairs[0]] + [synthetic_pair(W, H, seed=4321 + i, amp=4.0)[:2] + (np.zeros((2, H, W), np.float32),) for i in range(1, n4)]
+        # the share of rank 0 (and, for eight pairs, rank 1) of the 32-pair job at G = 8: global pairs 0, 8, 16, 24 (1, 9, 17, 25) --
+        # three of the reference's example pairs and one synthetic pair each
+        from util import load_rgb_planar, reference_pairs
+        real = reference_pairs()
+        ps = []
+        for g in [r + 8 * i for r in range((n4 + 3) // 4) for i in range(4)][:n4]:
+            if g == 0:
+                ps.append(pairs[0])
+            elif g < len(real) and os.path.exists(real[g][1]):
+                i0n, i1n = ctx.preprocess_global(load_rgb_planar(real[g][1]), load_rgb_planar(real[g][2]))
+                ps.append((i0n, i1n, np.zeros((2, H, W), np.float32)))
+            else:
+                ps.append(synthetic_pair(W, H, seed=1234 + g, amp=4.0)[:2] + (np.zeros((2, H, W), np.float32),))
         for i, (i0n, i1n, u0) in enumerate(ps):
             b.upload(i, i0n, i1n, u0)
         prm = dict(warps=WARPS, max_inner=INNER, tol_stop=0)
@@ -408,7 +430,7 @@ def batch_leg(out, args, F, np, ctx, pairs, synthetic_pair, n4):
                        "effective_GBps": round(px * BYTES_PER_PX_ITER * it_per_launch / (chunk_us * 1e-6) / 1e9, 1) if chunk_us > 0 else None,
                        "measured_frac": round(traffic / (chunk_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                        "warp_kernel_measured_traffic": _traffic(wk) if ok else None}}
-        if not args.no_cpu_baseline and n4 == 4:   # a bounded parity check of one synthetic pair of the batch (the -m gpu suite checks all four)
+        if not args.no_cpu_baseline and n4 == 4:   # a bounded parity check of the batch's last pair (the -m gpu suite checks all eighteen real ones)
             from oracle import oracle as O
             i0n, i1n, u0 = ps[n4 - 1]
             ou = O.tvl1_global(i0n, i1n, u0, warps=CHECK_WARPS, max_inner=INNER, tol_stop=False)[0]
@@ -647,7 +669,7 @@ def headline(args, world, npairs, value, dt_max, data_kind, per_rank, kern, pers
         "value": round(value, 1), "unit": "Mpx*iter/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": data_kind if world == 1 and npairs == 1 else "rank 0 pair 0: " + data_kind + "; others synthetic",
+        "data": data_kind,
         "config": {"workload": "TV-L1 global minimisation, %d pair(s)/GPU of %dx%d, %d warps x %d inner "
                                "iterations, tolerance stop off (BASELINE configs[1]%s)"
                                % (npairs, W, H, WARPS, INNER,

@@ -10,6 +10,8 @@ Also committed next to it:
                                            of BASELINE configs 1/2), copied verbatim as data files.
   sintel_final_hard_frame_000{2,3}.png  -- example_data/final/hard frames (a large-motion pair for the
                                            GPU == oracle test; no reference output recorded for it).
+  sintel_{clean,final}_{easy,medium,hard}_frame_000{1..4}.png -- (round 4) all six example sequences, frames 1-4: the 18 frame pairs
+                                           of SURVEY 8d's configs[3] input (example_frames() below; data files)
   known_answers.json                    -- what the compiled reference produced for whole solves
                                            (iteration counts, sha256 of the .flo), SURVEY.md App. D.
   sintel_{clean_easy,final_hard}_gt_frame_0002.npz -- the ground-truth flows the reference ships beside those frames
@@ -182,7 +184,24 @@ def ground_truth():
         print("wrote", os.path.basename(dst), gt.shape, os.path.getsize(dst), "bytes")
 
 
+def example_frames():
+    """The reference's six example sequences, frames 1..4 (example_data/{clean,final}/{easy,medium,hard}/frame_000N.png), copied
+    verbatim as data files: SURVEY 8d's configs[3] input is their 18 consecutive frame pairs (+ 14 synthetic).  1024x436 RGB PNGs,
+    12.9 MB in all."""
+    import shutil
+    root = "/root/reference/example_data"
+    for render in ("clean", "final"):
+        for level in ("easy", "medium", "hard"):
+            for k in range(1, 5):
+                src = os.path.join(root, render, level, "frame_%04d.png" % k)
+                dst = os.path.join(HERE, "sintel_%s_%s_frame_%04d.png" % (render, level, k))
+                if not os.path.exists(dst):
+                    shutil.copyfile(src, dst)
+                    print("copied", os.path.basename(dst), os.path.getsize(dst), "bytes")
+
+
 if __name__ == "__main__":
     main()
     models()
     ground_truth()
+    example_frames()

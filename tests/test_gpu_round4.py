@@ -219,3 +219,36 @@ def test_bench_per_rank_parity_path_rehearsed_on_one_gpu():
     assert chk[0]["bit_identical_to_cpu_first_30_warps"] is True
     assert line["epe_vs_cpu"]["bit_identical"] is True and line["value"] > 50000
     assert not line.get("secondary_errors"), line.get("secondary_errors")
+
+
+def test_all_eighteen_reference_pairs_match_the_checker_reference_defaults(ctx, oracle):
+    """SURVEY 8d's configs[3] input: the reference's six example sequences x frames 1->2, 2->3, 3->4 (committed fixtures), zero
+    initial flow, the reference's default schedule (5 warps, <= 400 iterations, tol 0.01).  All eighteen 1024x436 pairs in ONE
+    batch on the device (the pairs stop independently): per-pair iteration counts, errors, flow and duals bit-equal to the CPU
+    checker from the RGB frames on (device-side preprocessing included)."""
+    from util import load_rgb_planar, reference_pairs
+    pairs = reference_pairs()
+    assert len(pairs) == 18
+    b = F.Tvl1Batch(ctx, len(pairs), W, H)
+    try:
+        frames = []
+        for i, (name, fa, fb) in enumerate(pairs):
+            i0, i1 = load_rgb_planar(fa), load_rgb_planar(fb)
+            frames.append((i0, i1))
+            b.upload_images(i, i0, i1, np.zeros((2, H, W), np.float32))
+        iters, errs, ms, launches = b.solve()
+        assert not b.last_persistent()
+        counts = []
+        for i, (name, _, _) in enumerate(pairs):
+            i0n, i1n = oracle.preprocess_global(*frames[i])
+            ou, oit, oerr, oxi = oracle.tvl1_global(i0n, i1n, np.zeros((2, H, W), np.float32))
+            u, xi = b.download(i, want_xi=True)
+            assert list(iters[i]) == list(oit), (name, iters[i], oit)
+            assert bits_equal(errs[i], oerr), name
+            assert bits_equal(u, ou), (name, mismatch_report(u, ou))
+            assert bits_equal(xi, oxi), (name, mismatch_report(xi, oxi))
+            counts.append(int(iters[i].sum()))
+        print("18 reference pairs, reference defaults: %.1f ms on the device, iterations per pair %s" % (ms, counts))
+        assert len(set(counts)) > 6
+    finally:
+        b.close()

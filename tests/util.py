@@ -29,6 +29,20 @@ def sintel_pair(crop=None):
     return i0, i1
 
 
+def reference_pairs():
+    """The 18 frame pairs of SURVEY 8d's configs[3] input: the reference's six example sequences (clean / final x easy / medium /
+    hard), frames 1->2, 2->3, 3->4 -- committed fixtures.  The headline's pair (clean/easy 2->3) comes first.
+    Returns [(name, path of I0, path of I1)]."""
+    out = []
+    for render in ("clean", "final"):
+        for level in ("easy", "medium", "hard"):
+            for k in (2, 1, 3):
+                out.append(("%s/%s %d->%d" % (render, level, k, k + 1),
+                            os.path.join(GOLDEN, "sintel_%s_%s_frame_%04d.png" % (render, level, k)),
+                            os.path.join(GOLDEN, "sintel_%s_%s_frame_%04d.png" % (render, level, k + 1))))
+    return out
+
+
 def flo_sha256(flow):
     import faldoi_ipol_amd as F
     return hashlib.sha256(F.flo.flo_bytes(flow)).hexdigest()
