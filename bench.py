@@ -767,17 +767,20 @@ def nltvcsad_leg(out, F, np, ctx, pairs, rgb0):
                    "= 148 planes x 4 B"}
     k = cnt.get("nl_fused_kernel", {})
     if "FETCH_SIZE_KB" in k:
-        ok = within_drift(us_per_iter, prof_us(k))
+        # (one launch per iteration: the live figure is solve time / 400 and so holds the ~2 us between two dependent launches and the two
+        # per-warp kernels, the profiled one is the kernel alone -- compared with an allowance of 8 % instead of the 5 % of the TV-L1 legs)
+        ok = bool(prof_us(k)) and abs(us_per_iter - prof_us(k)) <= 0.08 * prof_us(k)
         tr = int((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024)
         tiles = int(k.get("grid_threads", 0) // max(1, k.get("workgroup", 1)))
         leg["nl_fused_kernel"] = {"launch_us_rocprof": prof_us(k), "counters_used": bool(ok),
                                   "measured_traffic_bytes_per_launch": tr if ok else None,
                                   "measured_traffic_over_algorithmic": round(tr / float(nb * W * H), 3) if ok else None,
-                                  "measured_hbm_frac": round(tr / (us_per_iter * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if ok else None,
+                                  "measured_hbm_frac": round(tr / (prof_us(k) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if ok else None,
                                   "valu_instr_per_launch": k.get("SQ_INSTS_VALU") if ok else None,
-                                  "valu_frac": round(k["SQ_INSTS_VALU"] / (us_per_iter * 1e-6) / 1e9 / VALU_PEAK_GINSTR, 4)
+                                  "valu_frac": round(k["SQ_INSTS_VALU"] / (prof_us(k) * 1e-6) / 1e9 / VALU_PEAK_GINSTR, 4)
                                   if ok and k.get("SQ_INSTS_VALU") else None,
-                                  "valu_busy": valu_busy(k, us_per_iter, tiles) if ok else None}
+                                  "valu_busy": valu_busy(k, prof_us(k), tiles) if ok else None,
+                                  "fractions_over": "the kernel's own (profiled, median) duration"}
     out.setdefault("secondary", {})["nltvcsad_1024x436_1warp_x_400"] = leg
 
 
