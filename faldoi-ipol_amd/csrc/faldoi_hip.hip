@@ -12,6 +12,7 @@
 #include "nltv_fused_kernel.hpp"
 #include "local_kernels.hpp"
 #include "grow_kernels.hpp"
+#include "grow_twin_kernel.hpp"
 
 #include <hip/hip_runtime.h>
 

@@ -118,11 +118,15 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// t: the thread's index within the 128 threads that work on this window (threadIdx.x, or threadIdx.x & 127 in the twin kernel);
+// on = false (twin kernel: this half has no window to fill in this step): nothing but the workgroup barrier at the end.
 __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float *out, size_t pe, const int *fixed, int nx,
-                                                     int ii, int ij, int pw, int ph, float &u1, float &u2, GrowStamp &gs)
+                                                     int ii, int ij, int pw, int ph, float &u1, float &u2, GrowStamp &gs,
+                                                     int t, bool on = true)
 {
-    const int t = threadIdx.x, c = t >> 6, lane = t & 63;
+    const int c = t >> 6, lane = t & 63;
     const int g = lane >> 4, i = lane & 15;
+    if (on) {
     int ws[kElapLevels], hs[kElapLevels], off[kElapLevels];
     ws[0] = pw; hs[0] = ph; off[0] = 0;
 #pragma unroll
@@ -281,10 +285,11 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         gs.mark(s == 0 ? 5 : 6);
     }
     if (lane == 0) sm.res[c] = (int)(coarse - sm.ver[c][0]);        // where this channel's level-0 solution lies
+    }                                                               // (on)
     __syncthreads();
     u1 = 0.0f;
     u2 = 0.0f;
-    if (t < pw * ph) {
+    if (on && t < pw * ph) {
         u1 = sm.ver[0][0][sm.res[0] + t];
         u2 = sm.ver[1][0][sm.res[1] + t];
     }
@@ -304,12 +309,25 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
 // weight != nullptr: the weighted functional, guided_tvl2coupled_w (src/tvl2w_model.cpp:254-455): l_t is scaled per
 // pixel by weight[row] * weight[column] (:379), lambda is divided by weight[w_radio + 1]^2 with the radius in force
 // during the call (src/energy_model.cpp:744-745), and the data energy is weighted (:227, a double product).
+// TWIN (grow_twin_kernel.hpp): two windows are minimised side by side by the two halves of a 256-thread workgroup.  Every workgroup
+// barrier below is then reached by both halves the same number of times: the iteration loop runs while EITHER half goes on (each half
+// reads the other's maxima from its LDS block `other` to know), a half that is idle (`on` = false) or has stopped only keeps the
+// barriers.  tw.defer: the window's results are not stored (the caller commits them later from the registers returned in tw.d1 / d2).
+// Without TWIN the function is what it was: t = threadIdx.x, one window, its own loop.
+struct TwinArgs {
+    int t;                      // thread index within the half (0..127)
+    bool on, other_on, defer;
+    GrowShared *other;
+    float d1, d2;               // out (defer): the thread's two divergence entries
+};
+template <bool TWIN = false>
 __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_t pe, int nx, int ny, int ii, int ij, int ei,
                                               int ej, int max_iter_patch, float &u1, float &u2, const float *weight, int iiw,
-                                              int ijw, int wr_call, int shadow, GrowStamp &gs)
+                                              int ijw, int wr_call, int shadow, GrowStamp &gs, TwinArgs *tw = nullptr)
 {
-    const int pw = ei - ii, ph = ej - ij, t = threadIdx.x;
-    const bool act = t < pw * ph;
+    const int pw = ei - ii, ph = ej - ij, t = TWIN ? tw->t : (int)threadIdx.x;
+    const bool on = !TWIN || tw->on;
+    const bool act = on && t < pw * ph;
     const int k = ii + (act ? t % pw : 0), l = ij + (act ? t / pw : 0);
     const int p = l * nx + k;
     const float theta = 0.3f, tau = 0.125f, tol_OF = 0.01f;                       // src/energy_model.cpp:704-709
@@ -367,13 +385,16 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
     sm.b[t] = ub2;
     __syncthreads();
     gs.mark(8);
-    int it = 0;
+    int it = 0, it_o = 0;
     float err_D = __builtin_inff();
     // The per-pixel steps are the ones of the global solver (faldoi_device.hpp): same expressions as
     // src/tvl2_model.cpp:364-427, with the exact-quotient sequences instead of the IEEE divide.
-    while (err_D > tol_OF * tol_OF && it < max_iter_patch) {                      // src/tvl2_model.cpp:359
-        ++it;
-        if (act) {
+    bool go = on && max_iter_patch > 0;                                           // src/tvl2_model.cpp:359 (err_D starts at infinity)
+    bool go_o = TWIN && tw->other_on && max_iter_patch > 0;
+    while (go || go_o) {
+        it += go ? 1 : 0;
+        it_o += go_o ? 1 : 0;
+        if (act && go) {
             threshold_step(rc, wx, wy, gr, rgrad, u1, u2, l_t, v1, v2);           // :364-391
             // forward_gradient_patch (src/utils.cpp:175-220) + tvl2coupled_getD (:82-115)
             const float ar = sm.a[ridx], ad = sm.a[didx], br = sm.b[ridx], bd = sm.b[didx];
@@ -384,7 +405,7 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
         sm.x[0][t] = x11; sm.x[1][t] = x12; sm.x[2][t] = x21; sm.x[3][t] = x22;
         __syncthreads();
         float uNr = 0.0f;
-        if (act) {
+        if (act && go) {
             if (fresh) {                                                          // divergence_patch, src/utils.cpp:63-113
                 const float nl11 = -sm.x[0][lidx], nl21 = -sm.x[2][lidx], nt12 = -sm.x[1][tidx], nt22 = -sm.x[3][tidx];
                 const float s1 = (selP_left ? nl11 : x11) + (selQ_left ? nl11 : (selQ_up ? nt12 : x12));
@@ -403,12 +424,20 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
             const float other = __shfl_xor(uNr, o, 64);
             uNr = other > uNr ? other : uNr;
         }
-        if ((t & 63) == 0) sm.err[2 * (it & 1) + (t >> 6)] = __float_as_int(uNr);
+        if ((t & 63) == 0 && go) sm.err[2 * (it & 1) + (t >> 6)] = __float_as_int(uNr);
         sm.a[t] = ub1;
         sm.b[t] = ub2;
         __syncthreads();
-        const float e0 = __int_as_float(sm.err[2 * (it & 1)]), e1 = __int_as_float(sm.err[2 * (it & 1) + 1]);
-        err_D = e1 > e0 ? e1 : e0;
+        if (go) {
+            const float e0 = __int_as_float(sm.err[2 * (it & 1)]), e1 = __int_as_float(sm.err[2 * (it & 1) + 1]);
+            err_D = e1 > e0 ? e1 : e0;
+            go = err_D > tol_OF * tol_OF && it < max_iter_patch;
+        }
+        if (TWIN && go_o) {                                                       // the other half's decision, from its own maxima
+            const float o0 = __int_as_float(tw->other->err[2 * (it_o & 1)]), o1 = __int_as_float(tw->other->err[2 * (it_o & 1) + 1]);
+            const float err_o = o1 > o0 ? o1 : o0;
+            go_o = err_o > tol_OF * tol_OF && it_o < max_iter_patch;
+        }
     }
     __syncthreads();                                     // every read of ubar is done before u overwrites it
     gs.mark(9);
@@ -418,11 +447,14 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
     sm.b[t] = u2;
     __syncthreads();
     float term = 0.0f;
+    if (TWIN) { tw->d1 = d1; tw->d2 = d2; }
     if (act) {
-        base[L_U1 * pe + p] = u1;
-        base[L_U2 * pe + p] = u2;
-        D1[p] = d1;
-        D2[p] = d2;
+        if (!(TWIN && tw->defer)) {
+            base[L_U1 * pe + p] = u1;
+            base[L_U2 * pe + p] = u2;
+            D1[p] = d1;
+            D2[p] = d2;
+        }
         if (shadow) {
             // Partitioned runs change the domain between growings, so what is a border entry now may be an interior
             // (stale-read) entry later: the duals are kept in HBM and the statements of divergence_patch that land on
@@ -459,7 +491,7 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
     sm.t[t] = term;
     __syncthreads();
     float ener = 0.0f;
-    if (t == 0) {                                        // the reference accumulates in row-major order, in fp32
+    if (t == 0 && on) {                                  // the reference accumulates in row-major order, in fp32
         const int m = pw * ph;
         float4 v[(kPatchMax * kPatchMax + 3) / 4];       // all LDS reads in flight first, then the ordered sum
         const float4 *t4 = reinterpret_cast<const float4 *>(sm.t);
@@ -642,7 +674,7 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
     gs.mark(1);
     const long long c0 = clock64();
     if (fill) {
-        harmonic_fill_window(sm, D.out, pe, D.fixed, nx, ii, ij, pw, ph, u1, u2, gs);
+        harmonic_fill_window(sm, D.out, pe, D.fixed, nx, ii, ij, pw, ph, u1, u2, gs, t);
         if (t == 0) ++fills;
     } else if (act) {
         u1 = D.planes[L_U1 * pe + p];

@@ -290,9 +290,22 @@ extern "C" void orc_partial_get(int k, int *meta /* percent, iteration, part_idx
     if (flow) memcpy(flow, p.flow.data(), sizeof(float) * p.flow.size());
 }
 
+// Study hook (round 4): how often could the window of the NEXT candidate have been computed beside the current one?  After a pop the
+// queue's new top c' is looked at: it qualifies if it is not stale and its window does not overlap the current one; it "holds" if it is
+// still the top once the current window's candidates have been pushed (then it is the next pop and its window read nothing the current
+// one wrote).  A window that was served this way does not look ahead itself (the device pairs windows two by two).
+static long g_twin[6];     // windows, attempts, holds, stale top, overlapping top, displaced by a push
+extern "C" void orc_twin_stats(long *out, int reset) { for (int k = 0; k < 6; k++) { out[k] = g_twin[k]; if (reset) g_twin[k] = 0; } }
+static bool same_candidate(const Candidate &a, const Candidate &b)
+{
+    return a.i == b.i && a.j == b.j && memcmp(&a.u, &b.u, 4) == 0 && memcmp(&a.v, &b.v, 4) == 0 && memcmp(&a.sim, &b.sim, 4) == 0;
+}
+
 // local_growing, src/local_faldoi.cpp:891-1039
 void local_growing(Direction &d, int iteration, bool fwd = false, int part_idx = -1)
 {
+    bool twin_served = false;
+    Candidate twin_next{};
     const int w = d.w, n = d.w * d.h;
     int percent_print[5] = { 30, 70, 80, 95, 100 };                       // :896
     int fixed = 0;
@@ -314,7 +327,26 @@ void local_growing(Direction &d, int iteration, bool fwd = false, int part_idx =
             g_trace_len += 3;
         }
         fixed++;                                                          // :925
+        bool attempt = false;
+        Candidate peek{};
+        g_twin[0]++;
+        if (twin_served && same_candidate(c, twin_next)) {
+            twin_served = false;                                          // this window was computed beside its predecessor
+        } else {
+            twin_served = false;
+            if (!d.queue.empty()) {
+                peek = d.queue.top();
+                const int pp = peek.j * w + peek.i;
+                if (d.fixed[pp]) g_twin[3]++;
+                else if (std::abs(peek.i - c.i) <= 2 * d.wr && std::abs(peek.j - c.j) <= 2 * d.wr) g_twin[4]++;
+                else { attempt = true; g_twin[1]++; }
+            }
+        }
         add_neighbors(d, c.i, c.j, iteration, d.wr);
+        if (attempt) {
+            if (!d.queue.empty() && same_candidate(d.queue.top(), peek)) { g_twin[2]++; twin_served = true; twin_next = peek; }
+            else g_twin[5]++;
+        }
         spec_assign(d, iteration);
         if (g_partial_on) {                                               // :942-994
             float percent = 100 * fixed * 1.0 / size * 1.0;
