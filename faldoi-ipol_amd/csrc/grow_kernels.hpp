@@ -122,8 +122,10 @@ __device__ __forceinline__ void wave_sync()
 // on = false (twin kernel: this half has no window to fill in this step): nothing but the workgroup barrier at the end.
 __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float *out, size_t pe, const int *fixed, int nx,
                                                      int ii, int ij, int pw, int ph, float &u1, float &u2, GrowStamp &gs,
-                                                     int t, bool on = true)
+                                                     int t, bool on = true, int fix_xy = -1, float fix_u = 0.0f, float fix_v = 0.0f)
 {
+    // fix_xy >= 0 (twin kernel, a guessed window): that pixel counts as fixed with the flow (fix_u, fix_v) -- the candidate's own pixel,
+    // whose fix (:926-932) is only written to the planes when the guess is confirmed
     const int c = t >> 6, lane = t & 63;
     const int g = lane >> 4, i = lane & 15;
     if (on) {
@@ -141,7 +143,7 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         const int xy = (ij + q / pw) * nx + ii + q % pw;
         const int fx = fixed[xy];                                   // both loads in flight, then the selection
         const float val = src[xy];
-        in[q] = (fx == 1) ? val : __builtin_nanf("");
+        in[q] = (xy == fix_xy) ? (c ? fix_v : fix_u) : ((fx == 1) ? val : __builtin_nanf(""));
     }
     wave_sync();
     gs.mark(2);
@@ -309,15 +311,18 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
 // weight != nullptr: the weighted functional, guided_tvl2coupled_w (src/tvl2w_model.cpp:254-455): l_t is scaled per
 // pixel by weight[row] * weight[column] (:379), lambda is divided by weight[w_radio + 1]^2 with the radius in force
 // during the call (src/energy_model.cpp:744-745), and the data energy is weighted (:227, a double product).
-// TWIN (grow_twin_kernel.hpp): two windows are minimised side by side by the two halves of a 256-thread workgroup.  Every workgroup
-// barrier below is then reached by both halves the same number of times: the iteration loop runs while EITHER half goes on (each half
-// reads the other's maxima from its LDS block `other` to know), a half that is idle (`on` = false) or has stopped only keeps the
+// TWIN (grow_twin_kernel.hpp): up to kTwinMax windows are minimised side by side by the 128-thread slots of one workgroup.  Every
+// workgroup barrier below is then reached by all slots the same number of times: the iteration loop runs while ANY slot goes on (each
+// thread reads the other slots' maxima from their LDS blocks to know), a slot that is idle (`on` = false) or has stopped only keeps the
 // barriers.  tw.defer: the window's results are not stored (the caller commits them later from the registers returned in tw.d1 / d2).
 // Without TWIN the function is what it was: t = threadIdx.x, one window, its own loop.
+constexpr int kTwinMax = 4;     // windows a workgroup of the twin kernel computes side by side, at most
 struct TwinArgs {
-    int t;                      // thread index within the half (0..127)
-    bool on, other_on, defer;
-    GrowShared *other;
+    int t;                      // thread index within the slot's 128 threads
+    bool on, defer;             // this slot has a window in this step | its results are held back
+    int self;                   // this thread's slot
+    unsigned on_mask;           // bit q: slot q has a window in this step
+    GrowShared *all;            // the slots' LDS blocks
     float d1, d2;               // out (defer): the thread's two divergence entries
 };
 template <bool TWIN = false>
@@ -385,15 +390,18 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
     sm.b[t] = ub2;
     __syncthreads();
     gs.mark(8);
-    int it = 0, it_o = 0;
+    int it = 0, it_o[kTwinMax] = { 0, 0, 0, 0 };
     float err_D = __builtin_inff();
     // The per-pixel steps are the ones of the global solver (faldoi_device.hpp): same expressions as
     // src/tvl2_model.cpp:364-427, with the exact-quotient sequences instead of the IEEE divide.
     bool go = on && max_iter_patch > 0;                                           // src/tvl2_model.cpp:359 (err_D starts at infinity)
-    bool go_o = TWIN && tw->other_on && max_iter_patch > 0;
+    unsigned go_o = (TWIN && max_iter_patch > 0) ? (tw->on_mask & ~(1u << tw->self)) : 0u;       // the other slots that go on
     while (go || go_o) {
         it += go ? 1 : 0;
-        it_o += go_o ? 1 : 0;
+        if (TWIN) {
+#pragma unroll
+            for (int q = 0; q < kTwinMax; ++q) it_o[q] += (int)((go_o >> q) & 1u);
+        }
         if (act && go) {
             threshold_step(rc, wx, wy, gr, rgrad, u1, u2, l_t, v1, v2);           // :364-391
             // forward_gradient_patch (src/utils.cpp:175-220) + tvl2coupled_getD (:82-115)
@@ -433,10 +441,15 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
             err_D = e1 > e0 ? e1 : e0;
             go = err_D > tol_OF * tol_OF && it < max_iter_patch;
         }
-        if (TWIN && go_o) {                                                       // the other half's decision, from its own maxima
-            const float o0 = __int_as_float(tw->other->err[2 * (it_o & 1)]), o1 = __int_as_float(tw->other->err[2 * (it_o & 1) + 1]);
-            const float err_o = o1 > o0 ? o1 : o0;
-            go_o = err_o > tol_OF * tol_OF && it_o < max_iter_patch;
+        if (TWIN && go_o) {                                                       // the other slots' decisions, from their own maxima
+#pragma unroll
+            for (int q = 0; q < kTwinMax; ++q)
+                if ((go_o >> q) & 1u) {
+                    const int *e = tw->all[q].err;
+                    const float o0 = __int_as_float(e[2 * (it_o[q] & 1)]), o1 = __int_as_float(e[2 * (it_o[q] & 1) + 1]);
+                    const float err_o = o1 > o0 ? o1 : o0;
+                    if (!(err_o > tol_OF * tol_OF && it_o[q] < max_iter_patch)) go_o &= ~(1u << q);
+                }
         }
     }
     __syncthreads();                                     // every read of ubar is done before u overwrites it

@@ -1,21 +1,29 @@
-// grow_twin_kernel.hpp -- one growing, two windows at a time where the pop order allows it (round 4).
+// grow_twin_kernel.hpp -- one growing, several windows at a time where the pop order allows it (round 4).
 //
 // A growing is sequential: pop the best candidate, fix its pixel, fill and minimise the window around it, push its neighbours, pop
 // again (src/local_faldoi.cpp:891-937, :679-727).  One workgroup runs one growing, and a lone wavefront issues one instruction per
 // ~5 cycles: a window costs ~53 k cycles of which ~41 k are the fill and the minimisation (profiles/r04_growing_detail.md).
 //
-// What CAN run side by side without changing a bit: after candidate A has been popped, look at the queue's new top B.  If B's pixel is
-// not fixed and B's window does not overlap A's (|di| > 2 wr or |dj| > 2 wr), then -- provided B is still the top once A's candidates
-// have been pushed -- the sequential algorithm pops B next, and B's window reads nothing A's window wrote.  So a 256-thread workgroup
-// computes both windows at once, half 0 (threads 0..127) A's and half 1 B's, with B's results held back; wave 0 pushes A's
-// candidates exactly as before and then looks at the top: if it is B (the same element, bit for bit), B is popped, its results are
-// stored and its candidates pushed -- the heap has seen exactly the sequential operations, in the sequential order --; if not, B's
-// speculative fix (fixed / out / ene of its pixel) is undone and nothing of it remains.  On the example pairs 21-31 % of the windows
-// are served this way (oracle study hook orc_twin_stats: the top is stale in 20-28 % of the steps, overlaps in 19-30 %, is displaced
-// by a push in 0.5 %).
+// What CAN run side by side without changing a bit.  After candidate A has been popped, the queue already holds the candidates that
+// come next unless A's own pushes overtake them.  The first wavefront loads the queue's three top levels (seven elements, with their
+// pixels' fixed flags: one round trip) and walks them the way a heap hands out its elements in order -- a frontier that starts at the
+// root and grows by the children of whatever it takes -- writing down the EXPECTED next pops: a stale candidate (its pixel is fixed, or
+// an earlier guess of this step fixes it: the sequential loop pops and skips it, :912-916) or a window.  A window guess stands if its
+// window overlaps neither A's nor an earlier guess's (|di| > 2 wr or |dj| > 2 wr); the first one that overlaps ends the list -- it has
+// to see what the earlier windows write.  Up to K-1 guesses: slot 0 of the workgroup (threads 0..127) computes A's window, slot g the
+// g-th guess's, at the same time, from the same state; the guesses' results are HELD BACK.
 //
-// Both halves execute the same workgroup barriers: the window functions take the half's thread index and an `on` flag
-// (harmonic_fill_window, window_solve<true> in grow_kernels.hpp), and the iteration loop of window_solve runs while either half goes on.
+// Then the sequential order is replayed on the real queue.  A's candidates are pushed exactly as before.  For every expected pop in
+// turn: is the queue's top this very element, bit for bit?  A stale one is popped (it is stale whatever happens); a window guess is
+// popped, its results stored and its candidates pushed -- and only then is the next expectation tested, against the queue those
+// pushes have changed.  The first mismatch ends the replay.  Nothing of a guess exists outside the workgroup until it is confirmed:
+// its pixel's fix (fixed / out / ene, :926-932) lives in LDS, where the guess's own window reads it, and is written to the planes
+// together with the window's results.  The heap therefore sees exactly the sequential operations in the sequential order;
+// a guess that was wrong costs nothing but the idle lanes it occupied.  K = 2 serves 26 % of the windows this way on the final/hard
+// pair (one whole-image growing 42.2 -> 34.9 s), K = 4 more.
+//
+// All slots execute the same workgroup barriers: the window functions take the slot's thread index and an `on` flag
+// (harmonic_fill_window, window_solve<true> in grow_kernels.hpp), and the iteration loop of window_solve runs while any slot goes on.
 // TV-l2 coupled functionals (-m 0 / 1), no image partitions (their out-of-window divergence statements would break the disjointness).
 #pragma once
 #include "grow_kernels.hpp"
@@ -24,9 +32,14 @@
 
 namespace faldoi {
 
-struct TwinShared {
-    GrowShared h[2];
-    int ctl[16];          // 0 have A | 1, 2 A's pixel | 3 twin | 4, 5 B's pixel | 6 commit B | 8, 9 window energies (float bits) | 10, 11 filled
+constexpr int kTwinPeek = 7;          // queue elements looked at: the heap's three top levels
+constexpr int kTwinSeq = 7;           // expected pops written down, at most
+
+template <int K> struct TwinShared {
+    GrowShared h[K];
+    int ctl[8 + 4 * kTwinMax];        // 0 have A | 1 guesses | 2 queue size at exit | 8+4s.. per slot: pixel i, j | commit | energy bits
+    int filled[kTwinMax];
+    float cand[kTwinMax][4];          // a guess's candidate: sim, u, v (its pixel's fix, written to the planes only when confirmed)
 };
 
 // The four neighbours' state of a pixel, read by wave 0 ahead of the window computation (insert_candidates :497-537 needs it)
@@ -49,13 +62,16 @@ __device__ __forceinline__ void twin_neigh_load(const GrowDir &D, int nx, int ny
     }
     n.cene = D.ene[j * nx + i];
 }
-// insert_candidates (:497-537) + the centre's update (:718-726) for one window, by wave 0; sm = the LDS block of the half that
+// insert_candidates (:497-537) + the centre's update (:718-726) for one window, by wave 0; sm = the LDS block of the slot that
 // minimised it (flow of the window in sm.a / sm.b), ener0 = its energy (wave-uniform)
-__device__ __forceinline__ void twin_push(const GrowDir &D, GrowShared &sm, size_t pe, int nx, int i, int j, int ii, int ij, int pw,
-                                          float ener0, const TwinNeigh &n, const HeapRef &heap, int &heap_size)
+__device__ __forceinline__ void twin_push(const GrowDir &D, GrowShared &sm, size_t pe, int nx, int ny, int i, int j, int wr, float ener0,
+                                          const TwinNeigh &n, const HeapRef &heap, int &heap_size)
 {
     const int nbx[4] = { 0, 0, 1, -1 }, nby[4] = { 1, -1, 0, 0 };
     const int t = threadIdx.x;
+    const int ii = (i - wr < 0) ? 0 : i - wr, ij = (j - wr < 0) ? 0 : j - wr;
+    const int pw = ((i + 1 + wr > nx) ? nx : i + 1 + wr) - ii;
+    (void)ny;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int px = i + nbx[q], py = j + nby[q];
@@ -75,17 +91,35 @@ __device__ __forceinline__ void twin_push(const GrowDir &D, GrowShared &sm, size
     }
 }
 
-__global__ __launch_bounds__(2 * kPatchThreads) void grow_kernel_twin(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr,
+__device__ __forceinline__ cand4 twin_lane_cand(const cand4 c, int lane)          // lane: wave-uniform
+{
+    cand4 r;
+    r.x = lane_read(c.x, lane);
+    r.y = lane_read(c.y, lane);
+    r.z = lane_read(c.z, lane);
+    r.w = lane_read(c.w, lane);
+    return r;
+}
+__device__ __forceinline__ bool twin_same(const cand4 a, const cand4 b)
+{
+    return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+           __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
+}
+
+template <int K>
+__global__ __launch_bounds__(K * kPatchThreads) void grow_kernel_twin(const GrowDir *__restrict__ dirs, int mode, int iteration, int wr,
                                                                      int max_iter_patch, int budget, int ntop)
 {
-    __shared__ TwinShared S;
+    static_assert(K >= 2 && K <= kTwinMax, "slots per workgroup");
+    __shared__ TwinShared<K> S;
     extern __shared__ __attribute__((aligned(16))) unsigned char grow_heap_top[];     // ntop queue elements (dynamic LDS, host-sized)
     const GrowDir D = dirs[blockIdx.x];
     const HeapRef heap{ (heap_ptr)D.heap, (heap_lds_ptr)(reinterpret_cast<cand4 *>(grow_heap_top)), ntop };
     heap_top_in(heap, D.ctl->heap_size);
+    if (threadIdx.x < 8 + 4 * kTwinMax) S.ctl[threadIdx.x] = 0;
     __syncthreads();
-    const int tid = threadIdx.x, half = tid >> 7, t = tid & (kPatchThreads - 1);
-    GrowShared &sm = S.h[half];
+    const int tid = threadIdx.x, slot = tid >> 7, t = tid & (kPatchThreads - 1), lane = tid & 63;
+    GrowShared &sm = S.h[slot];
     const int nx = D.nx, ny = D.ny;
     const size_t pe = D.pe;
     int heap_size = 0, seed_pos = 0;
@@ -99,12 +133,12 @@ __global__ __launch_bounds__(2 * kPatchThreads) void grow_kernel_twin(const Grow
     GrowStamp gs{ false, 0 };
     const int wr_eff = mode == 0 ? 1 : wr;
     while (windows < budget) {
-        // ---------------- the queue: pop A (as grow_body), look at the new top B
-        cand4 cB = { 0.0f, 0.0f, 0.0f, 0.0f }, cS = { 0.0f, 0.0f, 0.0f, 0.0f };
-        int stale_first = 0;                                                      // the top is a stale candidate cS; B is its guessed successor
-        float old_u = 0.0f, old_v = 0.0f, old_e = 0.0f;                           // B's pixel before the speculative fix (thread 0)
+        // ---------------- the queue: pop A (as grow_body), then write down the expected next pops
+        cand4 peek = { 0.0f, 0.0f, 0.0f, 0.0f };                                  // lane L < 7: queue element L (wave 0)
+        unsigned seq_nodes = 0u, seq_slots = 0u;                                  // expected pops, 3 + 2 bits each: queue element; 0 = stale / s = slot s's window
+        int nseq = 0, nguess = 0;
         if (tid < 64) {
-            int have = 0, g = 0, twin = 0, gB = 0;
+            int have = 0, g = 0;
             const long long c0 = clock64();
             if (mode == 0) {
                 if (seed_pos < D.nseeds) {
@@ -135,39 +169,69 @@ __global__ __launch_bounds__(2 * kPatchThreads) void grow_kernel_twin(const Grow
                     have = 1;
                     break;
                 }
-                if (have && heap_size > 0 && windows + 2 <= budget && !D.shadow) {
-                    cB = heap.ld(0);
-                    unsigned bij = __float_as_uint(cB.w);
-                    int bi = (int)(bij & 0xffffu), bj = (int)(bij >> 16);
-                    gB = bj * nx + bi;
-                    int fB = (gB == g) ? 1 : D.fixed[gB];
-                    if (fB && heap_size > 1) {
-                        // The top is stale (its pixel is fixed: the sequential loop pops it and goes on, :912-916).  Its successor is one
-                        // of the root's children -- a guess, checked like everything else once A's candidates are in: first the top
-                        // must still be this stale element (it is popped: it is stale whatever happens), then the new top must be B.
-                        cS = cB;
-                        stale_first = 1;
-                        const cand4 l = heap.ld(1), r = heap.ld(heap_size > 2 ? 2 : 1);
-                        cB = r.x < l.x ? r : l;
-                        bij = __float_as_uint(cB.w);
-                        bi = (int)(bij & 0xffffu);
-                        bj = (int)(bij >> 16);
-                        gB = bj * nx + bi;
-                        fB = (gB == g) ? 1 : D.fixed[gB];
+                int room = budget - windows - 1;                                  // windows this launch may still process beside A
+                if (room > K - 1) room = K - 1;
+                if (have && heap_size > 0 && room > 0 && !D.shadow) {
+                    // the three top levels of the queue and the state of their pixels, lane L <-> element L: one round trip
+                    const bool pv = lane < kTwinPeek && lane < heap_size;
+                    peek = heap.ld(pv ? lane : 0);
+                    const unsigned pij = __float_as_uint(peek.w);
+                    const int pgi = (int)(pij & 0xffffu), pgj = (int)(pij >> 16);
+                    const int pg = pgj * nx + pgi;
+                    const int pfx = (pg == g) ? 1 : D.fixed[pg];
+                    // the frontier walk (wave-uniform): take the smallest energy of the frontier, add its children
+                    int wi[kTwinMax] = { g % nx, 0, 0, 0 }, wj[kTwinMax] = { g / nx, 0, 0, 0 };   // pixels of this step's windows: A, guesses
+                    unsigned frontier = 1u;
+                    const int npeek = heap_size < kTwinPeek ? heap_size : kTwinPeek;
+#pragma unroll 1
+                    for (int stepk = 0; stepk < kTwinSeq && frontier != 0u && nguess < room; ++stepk) {
+                        int n = -1;
+                        float best = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < kTwinPeek; ++q) {
+                            const float sq = lane_read(peek.x, q);
+                            if (((frontier >> q) & 1u) && (n < 0 || sq < best)) { n = q; best = sq; }
+                        }
+                        frontier &= ~(1u << n);
+                        const int ni = __builtin_amdgcn_readlane(pgi, n), nj = __builtin_amdgcn_readlane(pgj, n);
+                        bool stale = __builtin_amdgcn_readlane(pfx, n) != 0;
+                        bool apart = true;
+#pragma unroll
+                        for (int sl = 0; sl < kTwinMax; ++sl)
+                            if (sl <= nguess) {
+                                const int di = ni - wi[sl], dj = nj - wj[sl];
+                                if (sl > 0 && di == 0 && dj == 0) stale = true;                // an earlier guess of this step fixes it
+                                apart = apart && (di > 2 * wr || di < -2 * wr || dj > 2 * wr || dj < -2 * wr);
+                            }
+                        if (!stale) {
+                            if (!apart) break;                                     // it must see the earlier windows' results: the list ends
+                            ++nguess;
+#pragma unroll
+                            for (int sl = 1; sl < kTwinMax; ++sl)
+                                if (sl == nguess) { wi[sl] = ni; wj[sl] = nj; }
+                        }
+                        seq_nodes |= (unsigned)n << (3 * nseq);
+                        seq_slots |= (unsigned)(stale ? 0 : nguess) << (2 * nseq);
+                        ++nseq;
+                        if (2 * n + 1 < npeek) frontier |= 1u << (2 * n + 1);      // its children join the frontier (those that were loaded)
+                        if (2 * n + 2 < npeek) frontier |= 1u << (2 * n + 2);
+                        if (2 * n + 1 >= kTwinPeek && 2 * n + 1 < heap_size) break;   // children that were not loaded: what follows is unknown
                     }
-                    const int di = bi - g % nx, dj = bj - g / nx;
-                    const bool apart = di > 2 * wr || di < -2 * wr || dj > 2 * wr || dj < -2 * wr;
-                    if (apart && fB == 0) {
-                        twin = 1;
-                        if (tid == 0) {                                           // B's fix (:926-932), undone below if B is not the next pop
-                            old_u = D.out[gB];
-                            old_v = D.out[pe + gB];
-                            old_e = D.ene[gB];
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the old values are in before the new ones leave)
-                            D.fixed[gB] = 1;
-                            D.out[gB] = cB.y;
-                            D.out[pe + gB] = cB.z;
-                            D.ene[gB] = cB.x;
+                    while (nseq > 0 && ((seq_slots >> (2 * (nseq - 1))) & 3u) == 0u) --nseq;   // (stale pops after the last guess are the next step's)
+                    // the guesses' candidates go to LDS: their pixels' fix (:926-932) is applied to the PLANES only when a guess is
+                    // confirmed; until then the guess's own window takes it from here (harmonic_fill_window: fix_xy)
+#pragma unroll
+                    for (int s = 1; s < kTwinMax; ++s) {
+                        if (s > nguess) continue;
+                        int node = 0;
+                        for (int q = 0; q < nseq; ++q) node = ((seq_slots >> (2 * q)) & 3u) == (unsigned)s ? (int)((seq_nodes >> (3 * q)) & 7u) : node;
+                        const cand4 c = twin_lane_cand(peek, node);
+                        if (tid == 0) {
+                            S.ctl[8 + 4 * s] = wi[s];
+                            S.ctl[9 + 4 * s] = wj[s];
+                            S.cand[s][0] = c.x;
+                            S.cand[s][1] = c.y;
+                            S.cand[s][2] = c.z;
                         }
                     }
                 }
@@ -175,126 +239,129 @@ __global__ __launch_bounds__(2 * kPatchThreads) void grow_kernel_twin(const Grow
             if (tid == 0) {
                 cyc[0] += clock64() - c0;
                 S.ctl[0] = have;
-                S.ctl[1] = g % nx;
-                S.ctl[2] = g / nx;
-                S.ctl[3] = twin;
-                S.ctl[4] = gB % nx;
-                S.ctl[5] = gB / nx;
+                S.ctl[1] = nguess;
+                S.ctl[8] = g % nx;
+                S.ctl[9] = g / nx;
             }
         }
         __syncthreads();
         if (!S.ctl[0]) { done = 1; break; }
-        const int twin = S.ctl[3];
-        const int iA = S.ctl[1], jA = S.ctl[2], iB = S.ctl[4], jB = S.ctl[5];
-        const int i = half ? iB : iA, j = half ? jB : jA;
-        const bool on = half == 0 || twin != 0;
+        const int ng = S.ctl[1];                                                  // guesses of this step (uniform)
+        const int i = S.ctl[8 + 4 * slot], j = S.ctl[9 + 4 * slot];
+        const bool on = slot <= ng;
 
-        // ---------------- the two windows (add_neighbors :679-727 up to the candidates)
+        // ---------------- the windows (add_neighbors :679-727 up to the candidates), one per slot
         const int ii = (i - wr_eff < 0) ? 0 : i - wr_eff, ij = (j - wr_eff < 0) ? 0 : j - wr_eff;          // get_index_patch
         const int ei = (i + 1 + wr_eff > nx) ? nx : i + 1 + wr_eff, ej = (j + 1 + wr_eff > ny) ? ny : j + 1 + wr_eff;
-        const int pw = ei - ii, ph = ej - ij;
+        const int pw = on ? ei - ii : 1, ph = on ? ej - ij : 1;
         const bool act = on && t < pw * ph;
         const int p = (ij + (act ? t / pw : 0)) * nx + ii + (act ? t % pw : 0);
         bool fill = iteration == 0;
-        if (iteration != 0) {                                                     // check_trustable_patch :639-656, per half
-            const int fa = __syncthreads_or(half == 0 && act && D.trust[p] == 0);
-            const int fb = __syncthreads_or(half == 1 && act && D.trust[p] == 0);
-            fill = (half ? fb : fa) != 0;
+        if (iteration != 0) {                                                     // check_trustable_patch :639-656, per slot
+            int f[K];
+#pragma unroll
+            for (int s = 0; s < K; ++s) f[s] = __syncthreads_or(slot == s && act && D.trust[p] == 0);
+            fill = f[slot] != 0;
         }
-        TwinNeigh nA, nB;
-        if (tid < 64) {                                                           // both windows' neighbour state, in flight during the windows
-            twin_neigh_load(D, nx, ny, iA, jA, nA);
-            if (twin) twin_neigh_load(D, nx, ny, iB, jB, nB);
+        TwinNeigh nb[K];
+        if (tid < 64) {                                                           // every window's neighbour state, in flight during the windows
+#pragma unroll
+            for (int s = 0; s < K; ++s)
+                if (s <= ng) {
+                    twin_neigh_load(D, nx, ny, S.ctl[8 + 4 * s], S.ctl[9 + 4 * s], nb[s]);
+                    if (s > 0) nb[s].cene = S.cand[s][0];                         // the centre's energy once its fix is in (:932)
+                }
         }
         float u1 = 0.0f, u2 = 0.0f;
         const long long c0 = clock64();
-        harmonic_fill_window(sm, D.out, pe, D.fixed, nx, ii, ij, pw, ph, u1, u2, gs, t, on && fill);
+        harmonic_fill_window(sm, D.out, pe, D.fixed, nx, ii, ij, pw, ph, u1, u2, gs, t, on && fill,
+                             (slot != 0 && on) ? j * nx + i : -1, S.cand[slot][1], S.cand[slot][2]);
         if (!fill && act) {
             u1 = D.planes[L_U1 * pe + p];
             u2 = D.planes[L_U2 * pe + p];
         }
         const long long c1 = clock64();
         const int iiw = (i - wr_eff < 0) ? -(i - wr_eff) : 0, ijw = (j - wr_eff < 0) ? -(j - wr_eff) : 0;    // get_relative_index_weight
-        TwinArgs tw{ t, on, half ? true : (twin != 0), half == 1, &S.h[1 - half], 0.0f, 0.0f };
+        TwinArgs tw{ t, on, slot != 0, slot, (2u << ng) - 1u, S.h, 0.0f, 0.0f };
         const float ener = window_solve<true>(sm, D.planes, pe, nx, ny, ii, ij, ei, ej, max_iter_patch, u1, u2, D.weight, iiw, ijw, wr_eff,
-                                              half == 0 ? D.shadow : 0, gs, &tw);
+                                              slot == 0 ? D.shadow : 0, gs, &tw);
         const long long c2 = clock64();
         if (t == 0) {
-            S.ctl[8 + half] = __float_as_int(ener);
-            S.ctl[10 + half] = fill ? 1 : 0;
+            S.ctl[11 + 4 * slot] = __float_as_int(ener);
+            S.filled[slot] = (on && fill) ? 1 : 0;
         }
 
-        // ---------------- A's candidates, then: is B the next pop?
+        // ---------------- A's candidates; then the expected pops are replayed on the real queue
         if (tid < 64) {
             const float enerA = lane_read(ener, 0);                               // thread 0 summed A's energy
-            twin_push(D, S.h[0], pe, nx, iA, jA, (iA - wr_eff < 0) ? 0 : iA - wr_eff, (jA - wr_eff < 0) ? 0 : jA - wr_eff,
-                      ((iA + 1 + wr_eff > nx) ? nx : iA + 1 + wr_eff) - ((iA - wr_eff < 0) ? 0 : iA - wr_eff), enerA, nA, heap, heap_size);
-            int commit = 0;
-            if (twin) {
-                auto is_top = [&](const cand4 c) {
-                    if (heap_size <= 0) return false;
-                    const cand4 top = heap.ld(0);
-                    return __float_as_uint(top.x) == __float_as_uint(c.x) && __float_as_uint(top.y) == __float_as_uint(c.y) &&
-                           __float_as_uint(top.z) == __float_as_uint(c.z) && __float_as_uint(top.w) == __float_as_uint(c.w);
-                };
-                bool same = true;
-                if (stale_first) {
-                    same = is_top(cS);
-                    if (same) {                                                   // the stale candidate goes, as in the sequential loop
-                        heap_remove_top_wave(heap, heap_size);
-                        ++pops;
-                    }
-                }
-                same = same && is_top(cB);
-                if (same) {
-                    heap_remove_top_wave(heap, heap_size);
-                    ++pops;
-                    commit = 1;
-                } else if (tid == 0) {                                            // B is not the next pop: its pixel as it was
-                    const int gB = jB * nx + iB;
-                    D.fixed[gB] = 0;
-                    D.out[gB] = old_u;
-                    D.out[pe + gB] = old_v;
-                    D.ene[gB] = old_e;
-                }
-            }
-            if (tid == 0) S.ctl[6] = commit;
+            twin_push(D, S.h[0], pe, nx, ny, S.ctl[8], S.ctl[9], wr_eff, enerA, nb[0], heap, heap_size);
         }
-        __syncthreads();
-        const int commit = twin ? S.ctl[6] : 0;
-        if (commit) {                                                             // uniform
-            if (half == 1 && act) {                                               // B's window, held back until now
-                D.planes[L_U1 * pe + p] = u1;
-                D.planes[L_U2 * pe + p] = u2;
-                D.planes[L_DIV1 * pe + p] = tw.d1;
-                D.planes[L_DIV2 * pe + p] = tw.d2;
-            }
+        int alive = 1;                                                            // wave 0: the replay has not met a mismatch yet
+        int q_next = 0;                                                           // wave 0: next entry of the expected sequence
+#pragma unroll 1
+        for (int s = 1; s <= ng; ++s) {                                           // uniform: ng comes from LDS
             if (tid < 64) {
-                const float enerB = __int_as_float(S.ctl[9]);
-                twin_push(D, S.h[1], pe, nx, iB, jB, (iB - wr_eff < 0) ? 0 : iB - wr_eff, (jB - wr_eff < 0) ? 0 : jB - wr_eff,
-                          ((iB + 1 + wr_eff > nx) ? nx : iB + 1 + wr_eff) - ((iB - wr_eff < 0) ? 0 : iB - wr_eff), enerB, nB, heap, heap_size);
+                int commit = 0;
+                while (alive && q_next < nseq) {
+                    const int node = (int)((seq_nodes >> (3 * q_next)) & 7u), sl = (int)((seq_slots >> (2 * q_next)) & 3u);
+                    if (sl != 0 && sl != s) break;                                // (cannot happen: guesses appear in slot order)
+                    const cand4 want = twin_lane_cand(peek, node);
+                    const bool same = heap_size > 0 && twin_same(heap.ld(0), want);
+                    if (!same) { alive = 0; break; }
+                    heap_remove_top_wave(heap, heap_size);                        // the stale candidate goes, or the guess is popped
+                    ++pops;
+                    ++q_next;
+                    if (sl == s) { commit = 1; break; }
+                }
+                if (!commit) alive = 0;                                           // (a guess that is not the next pop leaves nothing behind)
+                if (commit && tid == 0) {                                         // its pixel's fix, :926-932
+                    const int gs_ = S.ctl[9 + 4 * s] * nx + S.ctl[8 + 4 * s];
+                    D.fixed[gs_] = 1;
+                    D.out[gs_] = S.cand[s][1];
+                    D.out[pe + gs_] = S.cand[s][2];
+                    D.ene[gs_] = S.cand[s][0];
+                }
+                if (tid == 0) S.ctl[10 + 4 * s] = commit;
+            }
+            __syncthreads();
+            const int commit = S.ctl[10 + 4 * s];
+            if (commit) {                                                         // uniform
+                if (slot == s && act) {                                           // the guess's window, held back until now
+                    D.planes[L_U1 * pe + p] = u1;
+                    D.planes[L_U2 * pe + p] = u2;
+                    D.planes[L_DIV1 * pe + p] = tw.d1;
+                    D.planes[L_DIV2 * pe + p] = tw.d2;
+                }
+                if (tid < 64) {
+                    const float enerS = __int_as_float(S.ctl[11 + 4 * s]);
+                    TwinNeigh n = nb[1];
+#pragma unroll
+                    for (int q = 2; q < K; ++q) if (q == s) n = nb[q];
+                    twin_push(D, S.h[s], pe, nx, ny, S.ctl[8 + 4 * s], S.ctl[9 + 4 * s], wr_eff, enerS, n, heap, heap_size);
+                }
+                if (tid == 0) { ++solves; fills += S.filled[s]; }
+                ++windows;
             }
         }
         if (tid == 0) {
             ++solves;
-            fills += S.ctl[10];
-            if (commit) { ++solves; fills += S.ctl[11]; }
+            fills += S.filled[0];
             cyc[0] += clock64() - c2;
             cyc[1] += c1 - c0;
             cyc[2] += c2 - c1;
             if (mode == 0) {                                                      // :778-780
-                const int g = jA * nx + iA;
+                const int g = S.ctl[9] * nx + S.ctl[8];
                 D.out[g] = __builtin_nanf("");
                 D.out[pe + g] = __builtin_nanf("");
                 D.fixed[g] = 0;
             }
         }
-        windows += commit ? 2 : 1;
+        ++windows;
         __syncthreads();                                                          // S.ctl is rewritten by the next step's queue phase
     }
-    if (tid == 0) S.ctl[7] = heap_size;
+    if (tid == 0) S.ctl[2] = heap_size;
     __syncthreads();                                // (every queue operation of the first wavefront is behind its fence)
-    heap_top_out(heap, S.ctl[7]);
+    heap_top_out(heap, S.ctl[2]);
     if (tid == 0) {
         if (!done) done = (mode == 0) ? (seed_pos >= D.nseeds) : (heap_size == 0);
         D.ctl->heap_size = heap_size;

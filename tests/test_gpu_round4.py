@@ -253,3 +253,29 @@ def test_all_eighteen_reference_pairs_match_the_checker_reference_defaults(ctx, 
         assert len(set(counts)) > 6
     finally:
         b.close()
+
+
+def test_growing_with_several_windows_at_a_time_is_the_sequential_growing(ctx, oracle, monkeypatch):
+    """grow_twin_kernel.hpp: one growing computes up to K windows side by side where the pop order allows it (the next candidates of
+    the queue, guessed after a pop, held back, and committed only if they ARE the next pops once the earlier windows' candidates are
+    in).  K = 2 and K = 4 against the plain kernel (FALDOI_GROW_TWIN=0) and the CPU checker: flow, energy map and the counts of
+    pops / windows / fills identical -- whole image (plain and weighted functional), with saliency maps, with a tiny launch budget
+    (the guesses must respect it), on a tiny image."""
+    rng = np.random.default_rng(9)
+    for (w, h, x0, y0, kw) in ((160, 96, 300, 100, {}), (120, 80, 600, 250, dict(method=1)), (96, 64, 100, 300, dict(budget=7)),
+                               (9, 7, 50, 50, {}), (140, 90, 400, 60, dict(sal=True))):
+        a, b, go, ba = _partial_case(oracle, w, h, x0, y0, 21 + w)
+        okw = {k: v for k, v in kw.items() if k in ("method",)}
+        gkw = {k: v for k, v in kw.items() if k in ("method", "budget")}
+        sal = (rng.random((h, w)).astype(np.float32) + 0.5, rng.random((h, w)).astype(np.float32) + 0.5) if kw.get("sal") else (None, None)
+        want_flow, want_ene, want_st = oracle.local_faldoi(a, b, go, ba, sal0=sal[0], sal1=sal[1], **okw)
+        res = {}
+        for k in ("0", "2", "4"):
+            monkeypatch.setenv("FALDOI_GROW_TWIN", k)
+            flow, ene, st = ctx.match_growing(a, b, go, ba, sal[0], sal[1], preprocessed=1, **gkw)
+            res[k] = (flow, ene, (list(st.pops), list(st.solves), list(st.fills)))
+            assert bits_equal(flow, want_flow), (w, h, kw, k, mismatch_report(flow, want_flow))
+            assert bits_equal(ene, want_ene), (w, h, kw, k)
+            assert [int(v) for v in want_st] == [st.pops[0], st.solves[0], st.fills[0], st.pops[1], st.solves[1], st.fills[1]], (k, list(want_st), res[k][2])
+        monkeypatch.delenv("FALDOI_GROW_TWIN")
+        assert res["0"][2] == res["2"][2] == res["4"][2]
