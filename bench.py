@@ -861,6 +861,29 @@ def local_step_leg(out, args, F, np, ctx, full0, full1):
         "size": "%dx%d" % (W, H), "mode": "-split_img 1 -h_parts 3 -v_parts 2 (the reference's partition mode)",
         "windows": int(sum(st1.solves)), "device_ms": round(st1.growing_ms, 1),
         "windows_per_s": round(sum(st1.solves) / (st1.growing_ms * 1e-3), 0)}
+    # One WHOLE-IMAGE growing (the reference's default, -split_img 0), bounded: a 512x256 crop of the large-motion final/hard pair, device
+    # (up to four windows at a time where the pop order allows it, grow_twin_kernel.hpp) against the CPU checker on two threads
+    fh2, fh3 = os.path.join(ROOT, "tests", "golden", "sintel_final_hard_frame_0002.png"), os.path.join(ROOT, "tests", "golden", "sintel_final_hard_frame_0003.png")
+    if os.path.exists(fh2) and os.path.exists(fh3):
+        from util import load_rgb_planar
+        crop = (256, 100, 512, 256)
+        c0, c1 = load_rgb_planar(fh2, crop), load_rgb_planar(fh3, crop)
+        ca, cb = ctx.preprocess_local(c0, c1)
+        csd = seeds_from_dense(ctx, np, np.random.default_rng(1), ca, cb, crop[3], crop[2], 5)
+        t0 = time.perf_counter()
+        wflow, _, wst = ctx.match_growing(ca, cb, csd[0], csd[1], preprocessed=1)
+        t_dev = time.perf_counter() - t0
+        leg = {"size": "%dx%d crop of final/hard" % (crop[2], crop[3]), "mode": "-split_img 0 (whole image: forward and backward growing, two workgroups)",
+               "windows": int(sum(wst.solves)), "device_s": round(t_dev, 2), "windows_per_s": round(sum(wst.solves) / t_dev, 0),
+               "kernel": "grow_kernel_twin<4> (guessed next pops computed beside the current window, committed in pop order)"}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            t0 = time.perf_counter()
+            oflow, _, ost = O.local_faldoi(ca, cb, csd[0], csd[1])
+            t_cpu = time.perf_counter() - t0
+            leg.update({"cpu_checker_s": round(t_cpu, 2), "cpu_threads": 2, "device_over_cpu_time": round(t_dev / t_cpu, 3),
+                        "bit_identical": bool(np.array_equal(wflow.view(np.uint32), oflow.view(np.uint32)))})
+        out["secondary"]["local_whole_image_growing_one_pair"] = leg
     # BASELINE configs[2]'s chain on this pair, bounded: the local step above (in the reference's partition mode) followed by
     # the global step with the reference's defaults, from the frames in host memory to the final flow in host memory
     t0 = time.perf_counter()
