@@ -557,7 +557,7 @@ typedef __attribute__((address_space(3))) cand4 *heap_lds_ptr;
 struct HeapRef {
     heap_ptr g;
     heap_lds_ptr top;
-    int ntop;
+    int ntop;                         // 2^L - 1 (whole levels) or 0
     __device__ __forceinline__ cand4 ld(int i) const
     {
         cand4 v;
@@ -590,7 +590,20 @@ __device__ __forceinline__ void heap_sift_up_wave(const HeapRef &h, int hole, co
     while (hole > 0) {
         const bool have = lane < 24 && ((hole + 1) >> (lane + 1)) > 0;        // lane q <-> q-th ancestor
         const int aidx = have ? ((hole + 1) >> (lane + 1)) - 1 : 0;
-        const cand4 mine = h.ld(aidx);
+        // (both memories asked at once, into registers of their own: HeapRef::ld's two-sided form waits for the global answer
+        // before it asks LDS)
+        // -- every lane asks both, the one that does not hold its element for a slot that exists all the same: the queue's array
+        // is allocated from slot 0 on, its top merely stale while the kernel runs)
+        const bool in_top = aidx < h.ntop;
+        const cand4 below = h.g[aidx];
+        cand4 mine = below;
+        if (h.ntop > 0) {
+            const cand4 above = h.top[in_top ? aidx : 0];
+            mine.x = in_top ? above.x : below.x;
+            mine.y = in_top ? above.y : below.y;
+            mine.z = in_top ? above.z : below.z;
+            mine.w = in_top ? above.w : below.w;
+        }
         const unsigned long long down = __builtin_amdgcn_ballot_w64(have && mine.x > value.x);
         const int m = __builtin_ctzll(~down);                                 // leading ancestors that move down
         if (lane < m) h.st(((hole + 1) >> lane) - 1, mine);                   // into the slot of ancestor lane-1 (the hole for lane 0)
@@ -608,42 +621,195 @@ __device__ __forceinline__ void heap_push_wave(const HeapRef &h, int &size, int 
     ++size;
 }
 
+// One round of a pop's descent (std::__adjust_heap), at most six levels.  A pop is bounded by the instructions ONE wavefront can
+// issue (tools/heap_cycles.py: the same ~5.5 k cycles whether the queue lies in LDS or in global memory), so the round is built
+// to need few of them and no traffic between the register files inside the walk:
+//   * lane L holds node L of the hole's subtree in heap numbering (0: the hole itself, children of L: 2L+1, 2L+2; depths 0..5 in
+//     lanes 0..62), a second register holds depth 6 (lanes 0..63).  Besides its element, every lane requests the ENERGIES OF ITS
+//     NODE'S TWO CHILDREN (two more 4-byte loads, in flight with the others: one round trip per round);
+//   * ONE vector comparison then decides, for all 63 nodes at once, which child std::__adjust_heap would take there
+//     (`comp(right, left)`: the float comparison as written), and lands in a scalar register pair as a bit mask; a second mask
+//     says which nodes have two children at all;
+//   * the walk is scalar bit arithmetic on those masks -- rel = 2 rel + 1 + bit(rel) -- and marks the path's lanes;
+//   * the marked lanes store their elements into their parents' slots.
+// (Built and measured before this form: a `readlane` pair and a compare per level, ~20 instructions a level with the moves between
+// the register files -- 5.5 k cycles a pop; the same with eight levels per trip, two and four more registers for depths 7 and 8 --
+// slower still: the selects and the 510 elements per pop cost more than the trip they save.)
+//
+// The round that reaches a leaf also does std::__push_heap's part without another trip: the parent chain of the final hole IS the
+// path just walked, its elements are in registers.  The lowest path element the value does not pass (`!(path.sim > value.sim)`)
+// and everything above it move up, everything below it stays, and the value drops into the slot that element leaves.  Only when
+// the value passes every path element of this round (or the path ends at the one node with a single child) does the caller fall
+// back to the general sift-up.  Returns true when the value has been placed.  All arguments wave-uniform.
+constexpr int kHeapRoundLevels = 6;
+#ifdef FALDOI_HEAP_STAMPS                                            // what-if build only (tools/heap_cycles.py): where a pop's cycles go
+__device__ unsigned long long g_heap_stamp[16];
+__device__ __forceinline__ unsigned long long *heap_stamp_acc() { __shared__ unsigned long long acc[16]; return acc; }
+#define HEAP_STAMP(k) do { const long long now_ = clock64(); if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(heap_stamp_acc() + (k), (unsigned long long)(now_ - hs_last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); hs_last = clock64(); } while (0)
+#define HEAP_STAMP_BEGIN long long hs_last = clock64()
+#else
+#define HEAP_STAMP(k) do { } while (0)
+#define HEAP_STAMP_BEGIN do { } while (0)
+#endif
+typedef __attribute__((address_space(1))) const float *heap_key_ptr;
+typedef __attribute__((address_space(3))) const float *heap_lds_key_ptr;
+
+// What a lane needs to know about its node of a round's subtree (it depends on the lane alone)
+struct HeapLane {
+    int d;                            // depth of node `lane` under the hole, 0..5 (lane 63: unused)
+    int parent;                       // its parent's node (lane 0: 0)
+    bool is_left;                     // an odd node is its parent's left child
+    unsigned long long line;          // the nodes from this one up to depth 1 (lanes 0 and 63: all bits -- never matched)
+};
+__device__ __forceinline__ HeapLane heap_lane()
+{
+    const int lane = threadIdx.x & 63;
+    HeapLane hl;
+    hl.d = 31 - __builtin_clz(lane + 1);
+    hl.parent = lane ? (lane - 1) >> 1 : 0;
+    hl.is_left = (lane & 1) != 0;
+    unsigned long long line = 0ull;
+    int x = lane;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (x >= 1) line |= 1ull << x;
+        x = x >= 1 ? (x - 1) >> 1 : 0;
+    }
+    hl.line = (lane >= 1 && lane <= 62) ? line : ~0ull;
+    return hl;
+}
+
+template <bool GLOBAL>
+__device__ __forceinline__ bool heap_descend_round(const HeapRef &h, int &hole, const int half, const int last, const int nl, cand4 &value,
+                                                   bool &have_value, const int single, const HeapLane &hl)
+{
+    HEAP_STAMP_BEGIN;
+    const int lane = threadIdx.x & 63;
+    const int d = hl.d;
+    const int idx0 = (hole << d) + lane, idx6 = (hole << 6) + 63 + lane;
+    const bool want0 = lane >= 1 && lane <= 62 && d <= nl && idx0 <= last;
+    const bool six = nl >= 6 && hole + 1 <= ((last + 1) >> 6);      // uniform: the subtree reaches depth 6
+    const bool dec = lane <= 62 && d < nl && idx0 < half;           // a node with two children below which the round may step
+    const int kid = 2 * idx0 + 1;
+    // (plain loads from the one memory the round's levels lie in -- HeapRef::ld's two-sided form makes every load wait for the one
+    // before it, both sides writing the same registers; this is why ntop must be 2^L - 1: whole levels)
+    const cand4 none = { 0.0f, 0.0f, 0.0f, 0.0f };
+    cand4 r0, r6 = none;
+    float kl, kr;
+    if (GLOBAL) {
+        const heap_key_ptr keys = (heap_key_ptr)h.g;
+        r0 = h.g[want0 ? idx0 : last];
+        kl = keys[4 * (size_t)(dec ? kid : last)];
+        kr = keys[4 * (size_t)(dec ? kid + 1 : last)];
+        if (six) r6 = h.g[idx6 <= last ? idx6 : last];
+        if (!have_value) {                                          // the queue's last element, behind the round's own requests
+            value = h.g[last + 1];
+            have_value = true;
+        }
+    } else {
+        const heap_lds_key_ptr keys = (heap_lds_key_ptr)h.top;
+        r0 = h.top[want0 ? idx0 : 0];
+        kl = keys[4 * (dec ? kid : 0)];
+        kr = keys[4 * (dec ? kid + 1 : 0)];
+        if (six) r6 = h.top[idx6 <= last ? idx6 : 0];
+    }
+    HEAP_STAMP(GLOBAL ? 4 : 0);                                     // addresses, loads issued
+    const unsigned long long two = __builtin_amdgcn_ballot_w64(dec);
+    const unsigned long long goes_right = __builtin_amdgcn_ballot_w64(!(kr > kl));      // comp(right, left) picks the left child
+    HEAP_STAMP(GLOBAL ? 5 : 1);                                     // loads arrived, decisions
+    // Seen from the children: node L is TAKEN if its parent has two children and goes L's way (parents are nodes 0..30: the masks'
+    // low words); it is ON THE PATH if it and every node above it, up to depth 1, are taken.
+    const unsigned takes_left = (unsigned)(two & ~goes_right), takes_right = (unsigned)(two & goes_right);
+    const bool taken = (((hl.is_left ? takes_left : takes_right) >> hl.parent) & 1u) != 0u;
+    const unsigned long long taken_mask = __builtin_amdgcn_ballot_w64(taken);
+    const bool onpath = (taken_mask & hl.line) == hl.line;
+    const unsigned long long pm = __builtin_amdgcn_ballot_w64(onpath);                  // (never empty: the hole has two children)
+    const int deep = 63 - __builtin_clzll(pm);                      // the path's lowest node among depths 1..5
+    int r = __builtin_popcountll(pm);                               // levels walked
+    int c6 = -1;                                                    // the lane of r6 on the path
+    if (r == 5 && ((two >> deep) & 1ull) != 0ull) {
+        c6 = 2 * deep + 1 + (int)((goes_right >> deep) & 1ull) - 63;
+        r = 6;
+    }
+    const int cur = c6 >= 0 ? (hole << 6) + 63 + c6 : (hole << r) + deep;
+    HEAP_STAMP(GLOBAL ? 6 : 2);                                     // walk
+    // the elements on the path move into their parents' slots -- all of them, unless the value can be placed from here
+    bool placed = false, move6 = c6 >= 0, stop6 = false;
+    int stop = 64;                                                  // the lane whose slot takes the value; path lanes above it stay
+    if (cur >= half && cur != single && have_value) {               // a leaf: __push_heap from here, on the path in registers
+        const float vkey = lane_read(value.x, 0);
+        if (c6 >= 0 && !(lane_read(r6.x, c6) > vkey)) {             // the value does not pass the leaf's parent-to-be
+            placed = true;
+            stop6 = true;
+        } else {
+            const unsigned long long stay = pm & ~__builtin_amdgcn_ballot_w64(r0.x > vkey);     // path elements the value does not pass
+            if (stay != 0ull) {                                     // the lowest of them (the path's lanes are in depth order)
+                placed = true;
+                stop = 63 - __builtin_clzll(stay);
+                move6 = false;
+            }
+        }
+    }
+    if (onpath && lane <= stop) {
+        if (GLOBAL) {
+            h.st((idx0 - 1) >> 1, r0);                              // (the hole itself may still lie in LDS)
+            if (lane == stop) h.g[idx0] = value;
+        } else {
+            h.top[(idx0 - 1) >> 1] = r0;
+            if (lane == stop) h.top[idx0] = value;
+        }
+    }
+    if (move6 && lane == c6) {
+        if (GLOBAL) {
+            h.g[(idx6 - 1) >> 1] = r6;
+            if (stop6) h.g[idx6] = value;
+        } else {
+            h.top[(idx6 - 1) >> 1] = r6;
+            if (stop6) h.top[idx6] = value;
+        }
+    }
+    hole = cur;
+    HEAP_STAMP(GLOBAL ? 7 : 3);                                     // placement, stores issued
+    return placed;
+}
+
 // Removes the top (the caller has read element 0); precondition: size > 0.
 __device__ __forceinline__ void heap_remove_top_wave(const HeapRef &h, int &size)
 {
-    const int lane = threadIdx.x & 63;
-    const int len = --size;
+    const int len = __builtin_amdgcn_readfirstlane(size) - 1;      // (the lanes hold the same counters: scalar control flow from here)
+    size = len;
     if (len == 0) return;
-    const cand4 value = h.ld(len);
+    HEAP_STAMP_BEGIN;
+    // the last element: from LDS if it lies there; otherwise requested by the first round below the LDS levels, behind its own loads
+    // (a request made here would be waited for before that round could issue anything)
+    cand4 value = { 0.0f, 0.0f, 0.0f, 0.0f };
+    bool have_value = len < h.ntop;
+    if (have_value) value = h.top[len];
     const int half = (len - 1) / 2;                                 // nodes below `half` have two children
     const int last = len - 1;
-    const int d = 31 - __builtin_clz(lane + 2);                     // depth of this lane's node under the hole, 1..5 (6: unused)
-    const int off = lane + 2 - (1 << d);
+    const int single = (len & 1) == 0 ? (len - 2) / 2 : -1;        // the one node with a single (left) child, if there is one
+    const int top_levels = 31 - __builtin_clz(h.ntop + 1);         // levels of the queue that live in LDS (ntop = 2^L - 1, or 0)
     int hole = 0;
-    while (hole < half) {
-        const int idx = ((hole + 1) << d) - 1 + off;
-        const cand4 mine = h.ld((d <= 5 && idx <= last) ? idx : last);
-        bool onpath = false;
-        int cur = hole, rel = 0;                                    // rel: position of `cur` within its level of the subtree
-#pragma unroll
-        for (int dd = 1; dd <= 5; ++dd) {
-            if (cur < half) {                                       // both children exist
-                const int left = (1 << dd) - 2 + 2 * rel;           // lane that holds the left child
-                const float sl = lane_read(mine.x, left), sr = lane_read(mine.x, left + 1);
-                const int right = (sr > sl) ? 0 : 1;                // comp(right, left) picks the left child
-                onpath = onpath || lane == left + right;
-                cur = 2 * cur + 1 + right;
-                rel = 2 * rel + right;
-            }
-        }
-        if (onpath) h.st((idx - 1) >> 1, mine);                     // every element of the path moves into its parent's slot
-        hole = cur;
+    bool placed = false;
+    const HeapLane hl = heap_lane();
+    HEAP_STAMP(8);                                                  // set-up
+    while (hole < half && !placed) {
+        const int in_lds = top_levels - (32 - __builtin_clz(hole + 1));        // levels below the hole that lie in LDS
+        if (in_lds >= 1) placed = heap_descend_round<false>(h, hole, half, last, in_lds < kHeapRoundLevels ? in_lds : kHeapRoundLevels, value, have_value, single, hl);
+        else placed = heap_descend_round<true>(h, hole, half, last, kHeapRoundLevels, value, have_value, single, hl);
     }
+#ifdef FALDOI_HEAP_STAMPS
+    hs_last = clock64();
+#endif
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    if ((len & 1) == 0 && hole == (len - 2) / 2) {                  // the one node with a single (left) child
+    HEAP_STAMP(9);                                                  // fence
+    if (placed) return;
+    HEAP_STAMP(10);
+    if (!have_value) value = h.g[len];                              // (a queue that ends on the last LDS level: no round below it was made)
+    if (hole == single) {
         const int child = 2 * (hole + 1);
         const cand4 c = h.ld(child - 1);
-        if (lane == 0) h.st(hole, c);
+        if ((threadIdx.x & 63) == 0) h.st(hole, c);
         hole = child - 1;
     }
     heap_sift_up_wave(h, hole, value);
@@ -910,11 +1076,19 @@ __global__ __launch_bounds__(kPatchThreads) void heap_replay_kernel(Candidate *h
     // vector registers
     extern __shared__ __attribute__((aligned(16))) unsigned char replay_heap_top[];
     const HeapRef h{ (heap_ptr)heap, (heap_lds_ptr)(reinterpret_cast<cand4 *>(replay_heap_top)), ntop };
+#ifdef FALDOI_HEAP_STAMPS
+    if (threadIdx.x < 16) heap_stamp_acc()[threadIdx.x] = 0ull;
+    __syncthreads();
+#endif
     if (threadIdx.x < 64) {
         int size = npopped[0], np = npopped[0];              // both 0 (the compiler cannot know)
+        long long cyc_push = 0, cyc_pop = 0, n_push = 0, n_pop = 0;      // shader-clock cycles per kind (tools/heap_cycles.py)
         for (int k = 0; k < nops; ++k) {
+            const long long c0 = clock64();
             if (ops[k]) {
                 heap_push_wave(h, size, k & 0xffff, (k * 7) & 0x1ff, sims[k] * 3.0f + 1.0f, -sims[k], sims[k]);
+                cyc_push += clock64() - c0;
+                ++n_push;
             } else if (size == 0) {
                 if (threadIdx.x == 0) popped[np] = -1;
                 ++np;
@@ -925,9 +1099,20 @@ __global__ __launch_bounds__(kPatchThreads) void heap_replay_kernel(Candidate *h
                 const bool intact = c.y == c.x * 3.0f + 1.0f && c.z == -c.x && (cw >> 16) == (((cw & 0xffffu) * 7) & 0x1ff);
                 if (threadIdx.x == 0) popped[np] = intact ? (int)(cw & 0xffffu) : -2;     // payload travels with its key
                 ++np;
+                if (k >= nops / 2) {                         // (the second half of the replay: the queue has its size by then)
+                    cyc_pop += clock64() - c0;
+                    ++n_pop;
+                }
             }
         }
-        if (threadIdx.x == 0) *npopped = np;
+        if (threadIdx.x == 0) {
+            *npopped = np;
+            long long *cyc = reinterpret_cast<long long *>(npopped + 2);
+            cyc[0] = cyc_push; cyc[1] = n_push; cyc[2] = cyc_pop; cyc[3] = n_pop;
+#ifdef FALDOI_HEAP_STAMPS
+            for (int k = 0; k < 16; ++k) g_heap_stamp[k] = heap_stamp_acc()[k];
+#endif
+        }
     }
 }
 

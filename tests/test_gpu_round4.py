@@ -279,3 +279,20 @@ def test_growing_with_several_windows_at_a_time_is_the_sequential_growing(ctx, o
             assert [int(v) for v in want_st] == [st.pops[0], st.solves[0], st.fills[0], st.pops[1], st.solves[1], st.fills[1]], (k, list(want_st), res[k][2])
         monkeypatch.delenv("FALDOI_GROW_TWIN")
         assert res["0"][2] == res["2"][2] == res["4"][2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("top_levels", [0, 2, 5, 9, 13])
+def test_device_queue_wide_rounds_and_in_register_placement(ctx, monkeypatch, top_levels):
+    # a pop below the LDS levels walks eight levels per trip (registers of depth 6, 7, 8) and places the last element from the path in
+    # registers; every split between LDS and global levels, ties, long runs of pops down to the empty queue, against the host queue
+    monkeypatch.setenv("FALDOI_HEAP_TOP_LEVELS", str(top_levels))
+    rng = np.random.default_rng(40 + top_levels)
+    for levels, n, ppush in ((3, 300, 0.6), (100000, 65000, 0.75), (7, 65000, 0.66), (1000, 40000, 0.52), (100000, 3000, 0.5)):
+        ops = (rng.random(n) < ppush).astype(np.int32)
+        ops[: n // 3] |= (rng.random(n // 3) < 0.8).astype(np.int32)      # grow first, then drain: pops from every depth
+        ops[-n // 4:] = 0
+        sims = rng.integers(0, levels, n).astype(np.float32) * 0.25
+        want = F.capi.queue_replay(ops, sims)
+        got = ctx.queue_replay(ops, sims)
+        assert np.array_equal(got, want), (top_levels, levels, n)
