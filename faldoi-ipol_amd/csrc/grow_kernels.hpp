@@ -176,8 +176,90 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
     }
     gs.mark(3);
     const float *coarse = fin;                                      // solution of the level below (level-relative indexing)
+    // Levels 2.. of a window of at most 11x11 have at most 3x3 pixels.  The pipelined sweeps below cost by their steps
+    // (w + h - 1 + 6 per level, ~290 cycles each: 11 steps for 3x3, 9 for 2x2), not by their pixels; for so few pixels the three
+    // sweeps run serially instead, in registers, every lane computing the same thing: the level sits in a 3x3 grid (lane e < 9 loads
+    // pixel (e % 3, e / 3)), nine `readlane`s spread it, an update is the statement of src/elap_recsep.c:50-69 in its written
+    // order with getpixel_1's clamping resolved per position (left / up at compile time, right / down by the level's size), the
+    // early exit is the reference's (`maxupdate < 1e-10` after a sweep).  One rolled loop over these levels: its body exists once.
+    {
+        int wc = 1, hc = 1;                                         // size of the level below
+#pragma unroll 1
+        for (int s = kElapLevels - 1; s >= 2; --s) {
+            const int w = (pw + (1 << s) - 1) >> s, h = (ph + (1 << s) - 1) >> s;      // ceil(ceil(w / 2) / 2 ...) = ceil(w / 2^s)
+            const int o = s == 2 ? off[2] : s == 3 ? off[3] : s == 4 ? off[4] : s == 5 ? off[5] : off[kElapLevels - 1];
+            static_assert(kElapLevels == 7 && kPatchMax == 11, "levels 2..6 of an at most 11x11 window");
+            const float *x = in + o;
+            if (w * h == 1) {
+                // a single pixel: its four neighbours clamp to itself; the three sweeps run in registers
+                if (lane == 0) {
+                    float v = x[0];
+                    if (!__builtin_isfinite(v)) {
+                        v = (s < kElapLevels - 1) ? coarse[0] : 0.0f;
+                        for (int it = 0; it < 3; ++it) {
+                            const float lap = -4 * v + v + v + v + v;
+                            const float nw = v + 0.4f * lap;
+                            const float update = __builtin_fabsf(v - nw);
+                            v = nw;
+                            if ((double)update < 1e-10) break;
+                        }
+                    }
+                    fin[o] = v;
+                }
+                coarse = fin + o;
+                wc = 1;
+                hc = 1;
+                wave_sync();
+                continue;
+            }
+            const int j3 = (lane * 11) >> 5, i3 = lane - 3 * j3;   // lane e < 9: (e % 3, e / 3)
+            const bool valid = lane < 9 && i3 < w && j3 < h;
+            const int q = valid ? j3 * w + i3 : 0;
+            const float xv = x[q];
+            float v = xv;
+            float coarse_v = 0.0f;                                  // coarsest level starts from zero
+            if (s < kElapLevels - 1) coarse_v = px_clamp(coarse, wc, hc, i3 >> 1, j3 >> 1);     // round((i - 0.5) / 2) == i / 2 for i >= 0
+            if (!__builtin_isfinite(v)) v = coarse_v;               // :113-114 with the initialisation of :204-222
+            const unsigned holes9 = (unsigned)__builtin_amdgcn_ballot_w64(valid && __builtin_isnan(xv));
+            if (holes9 != 0u) {
+                float V[9];
 #pragma unroll
-    for (int s = kElapLevels - 1; s >= 0; --s) {
+                for (int e = 0; e < 9; ++e) V[e] = lane_read(v, e);
+#pragma unroll 1
+                for (int it = 0; it < 3; ++it) {
+                    float mx = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) {
+                        const int ei = e % 3, ej = e / 3;
+                        if ((holes9 >> e) & 1u) {                   // (uniform)
+                            const float self = V[e];
+                            const float right = (ei < 2 && ei < w - 1) ? V[e + 1 < 9 ? e + 1 : e] : self;
+                            const float down = (ej < 2 && ej < h - 1) ? V[e + 3 < 9 ? e + 3 : e] : self;
+                            const float left = ei > 0 ? V[e > 0 ? e - 1 : e] : self;
+                            const float up = ej > 0 ? V[e > 2 ? e - 3 : e] : self;
+                            const float lap = -4 * self + right + down + left + up;
+                            const float res = self + 0.4f * lap;
+                            const float update = __builtin_fabsf(self - res);
+                            if (update > mx) mx = update;
+                            V[e] = res;
+                        }
+                    }
+                    if ((double)lane_read(mx, 0) < 1e-10) break;     // :66-67
+                }
+#pragma unroll
+                for (int e = 0; e < 9; ++e) v = (lane == e) ? V[e] : v;
+            }
+            float *dst = sm.ver[c][0] + o;
+            if (valid) dst[q] = v;
+            coarse = dst;
+            wc = w;
+            hc = h;
+            wave_sync();
+            gs.mark(6);
+        }
+    }
+#pragma unroll
+    for (int s = 1; s >= 0; --s) {
         const int w = ws[s], h = hs[s], o = off[s];
         const float *x = in + o;
         if (w * h == 1) {
