@@ -39,6 +39,7 @@ template <int K> struct TwinShared {
     GrowShared h[K];
     int ctl[8 + 4 * kTwinMax];        // 0 have A | 1 guesses | 2 queue size at exit | 8+4s.. per slot: pixel i, j | commit | energy bits
     int filled[kTwinMax];
+    int untrusted[2 * kTwinMax];      // per wavefront: its part of its slot's window has a pixel that is not trusted
     float cand[kTwinMax][4];          // a guess's candidate: sim, u, v (its pixel's fix, written to the planes only when confirmed)
 };
 
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(K * kPatchThreads) void grow_kernel_twin(const Grow
                     const int pfx = (pg == g) ? 1 : D.fixed[pg];
                     // the frontier walk (wave-uniform): take the smallest energy of the frontier, add its children
                     int wi[kTwinMax] = { g % nx, 0, 0, 0 }, wj[kTwinMax] = { g / nx, 0, 0, 0 };   // pixels of this step's windows: A, guesses
+                    int gnode[kTwinMax] = { 0, 0, 0, 0 };                         // the queue element each guess is
                     unsigned frontier = 1u;
                     const int npeek = heap_size < kTwinPeek ? heap_size : kTwinPeek;
 #pragma unroll 1
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(K * kPatchThreads) void grow_kernel_twin(const Grow
                             ++nguess;
 #pragma unroll
                             for (int sl = 1; sl < kTwinMax; ++sl)
-                                if (sl == nguess) { wi[sl] = ni; wj[sl] = nj; }
+                                if (sl == nguess) { wi[sl] = ni; wj[sl] = nj; gnode[sl] = n; }
                         }
                         seq_nodes |= (unsigned)n << (3 * nseq);
                         seq_slots |= (unsigned)(stale ? 0 : nguess) << (2 * nseq);
@@ -223,9 +225,7 @@ __global__ __launch_bounds__(K * kPatchThreads) void grow_kernel_twin(const Grow
 #pragma unroll
                     for (int s = 1; s < kTwinMax; ++s) {
                         if (s > nguess) continue;
-                        int node = 0;
-                        for (int q = 0; q < nseq; ++q) node = ((seq_slots >> (2 * q)) & 3u) == (unsigned)s ? (int)((seq_nodes >> (3 * q)) & 7u) : node;
-                        const cand4 c = twin_lane_cand(peek, node);
+                        const cand4 c = twin_lane_cand(peek, gnode[s]);
                         if (tid == 0) {
                             S.ctl[8 + 4 * s] = wi[s];
                             S.ctl[9 + 4 * s] = wj[s];
@@ -257,11 +257,14 @@ __global__ __launch_bounds__(K * kPatchThreads) void grow_kernel_twin(const Grow
         const bool act = on && t < pw * ph;
         const int p = (ij + (act ? t / pw : 0)) * nx + ii + (act ? t % pw : 0);
         bool fill = iteration == 0;
-        if (iteration != 0) {                                                     // check_trustable_patch :639-656, per slot
-            int f[K];
-#pragma unroll
-            for (int s = 0; s < K; ++s) f[s] = __syncthreads_or(slot == s && act && D.trust[p] == 0);
-            fill = f[slot] != 0;
+        if (iteration != 0) {                                                     // check_trustable_patch :639-656, per slot:
+            // every wavefront votes on its part of its slot's window, one barrier, the slot's two votes are read back (a
+            // __syncthreads_or per slot is two barriers and an LDS atomic each)
+            const bool mine = act && D.trust[p] == 0;
+            const unsigned long long vote = __builtin_amdgcn_ballot_w64(mine);
+            if (lane == 0) S.untrusted[tid >> 6] = vote != 0ull ? 1 : 0;
+            __syncthreads();
+            fill = (S.untrusted[2 * slot] | S.untrusted[2 * slot + 1]) != 0;
         }
         TwinNeigh nb[K];
         if (tid < 64) {                                                           // every window's neighbour state, in flight during the windows
