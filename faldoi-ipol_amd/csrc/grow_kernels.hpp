@@ -915,21 +915,18 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
     if (!fill) fill = __syncthreads_or(act && D.trust[p] == 0);                   // check_trustable_patch :639-656
     // first wavefront (uniformly): state of the four neighbours and of the centre, read now so that the latency
     // hides behind the window computation (only lane 0 ever writes these arrays during a growing)
+    // (lane q < 4 holds neighbour q's state, lane 4 the centre's: one set of loads for all five)
     const int nbx[4] = { 0, 0, 1, -1 }, nby[4] = { 1, -1, 0, 0 };                 // insert_candidates :501-505
-    int nfix[4] = { 1, 1, 1, 1 };
-    float nene[4] = { 0, 0, 0, 0 }, nsal[4] = { 1.0f, 1.0f, 1.0f, 1.0f }, cene = 0.0f;
+    int nfix = 1;
+    float nene = 0.0f, nsal = 1.0f;
     if (t < 64) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int px = i + nbx[q], py = j + nby[q];
-            const bool inside = px >= 0 && px < nx && py >= 0 && py < ny;
-            const int g = inside ? py * nx + px : j * nx + i;
-            const int f = D.fixed[g];
-            nfix[q] = inside ? f : 1;
-            nene[q] = D.ene[g];
-            if (D.sal) nsal[q] = D.sal[g];
-        }
-        cene = D.ene[j * nx + i];
+        const int px = i + (t == 2 ? 1 : t == 3 ? -1 : 0), py = j + (t == 0 ? 1 : t == 1 ? -1 : 0);
+        const bool inside = px >= 0 && px < nx && py >= 0 && py < ny;
+        const int g = inside ? py * nx + px : j * nx + i;
+        const int f = D.fixed[g];
+        nfix = inside ? f : 1;
+        nene = D.ene[g];
+        if (D.sal) nsal = D.sal[g];
     }
     float u1 = 0.0f, u2 = 0.0f;
     gs.mark(1);
@@ -964,8 +961,8 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int px = i + nbx[q], py = j + nby[q];
-            const float new_ener = ener0 * nsal[q];
-            if (!nfix[q] && new_ener < nene[q]) {                                 // outside the image: nfix = 1 (wave-uniform test)
+            const float new_ener = ener0 * lane_read(nsal, q);
+            if (!__builtin_amdgcn_readlane(nfix, q) && new_ener < lane_read(nene, q)) {       // outside the image: nfix = 1 (wave-uniform test)
                 if (t == 0) D.ene[py * nx + px] = ener0;
                 const int wq = (py - ij) * pw + (px - ii);                        // the neighbour lies in the window
                 if (heap_size < D.heap_cap) heap_push_wave(heap, heap_size, px, py, sm.a[wq], sm.b[wq], new_ener);
@@ -973,7 +970,7 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
             }
         }
         const int g = j * nx + i, wq = (j - ij) * pw + (i - ii);                  // :718-726
-        if (t == 0 && cene > ener0) {
+        if (t == 0 && lane_read(nene, 4) > ener0) {
             D.out[g] = sm.a[wq];
             D.out[pe + g] = sm.b[wq];
             D.ene[g] = ener0;

@@ -43,25 +43,22 @@ template <int K> struct TwinShared {
     float cand[kTwinMax][4];          // a guess's candidate: sim, u, v (its pixel's fix, written to the planes only when confirmed)
 };
 
-// The four neighbours' state of a pixel, read by wave 0 ahead of the window computation (insert_candidates :497-537 needs it)
+// The four neighbours' state of a pixel and its own energy, read by wave 0 ahead of the window computation (insert_candidates
+// :497-537 needs it): lane q < 4 holds neighbour q's, lane 4 the centre's -- one set of loads for all five
 struct TwinNeigh {
-    int nfix[4];
-    float nene[4], nsal[4], cene;
+    int nfix;
+    float nene, nsal;
 };
 __device__ __forceinline__ void twin_neigh_load(const GrowDir &D, int nx, int ny, int i, int j, TwinNeigh &n)
 {
-    const int nbx[4] = { 0, 0, 1, -1 }, nby[4] = { 1, -1, 0, 0 };                 // insert_candidates :501-505
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = i + nbx[q], py = j + nby[q];
-        const bool inside = px >= 0 && px < nx && py >= 0 && py < ny;
-        const int g = inside ? py * nx + px : j * nx + i;
-        const int f = D.fixed[g];
-        n.nfix[q] = inside ? f : 1;
-        n.nene[q] = D.ene[g];
-        n.nsal[q] = D.sal ? D.sal[g] : 1.0f;
-    }
-    n.cene = D.ene[j * nx + i];
+    const int q = threadIdx.x & 63;
+    const int px = i + (q == 2 ? 1 : q == 3 ? -1 : 0), py = j + (q == 0 ? 1 : q == 1 ? -1 : 0);     // insert_candidates :501-505
+    const bool inside = px >= 0 && px < nx && py >= 0 && py < ny;
+    const int g = inside ? py * nx + px : j * nx + i;
+    const int f = D.fixed[g];
+    n.nfix = inside ? f : 1;
+    n.nene = D.ene[g];
+    n.nsal = D.sal ? D.sal[g] : 1.0f;
 }
 // insert_candidates (:497-537) + the centre's update (:718-726) for one window, by wave 0; sm = the LDS block of the slot that
 // minimised it (flow of the window in sm.a / sm.b), ener0 = its energy (wave-uniform)
@@ -76,8 +73,8 @@ __device__ __forceinline__ void twin_push(const GrowDir &D, GrowShared &sm, size
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int px = i + nbx[q], py = j + nby[q];
-        const float new_ener = ener0 * n.nsal[q];
-        if (!n.nfix[q] && new_ener < n.nene[q]) {                                 // outside the image: nfix = 1 (wave-uniform test)
+        const float new_ener = ener0 * lane_read(n.nsal, q);
+        if (!__builtin_amdgcn_readlane(n.nfix, q) && new_ener < lane_read(n.nene, q)) {       // outside the image: nfix = 1 (wave-uniform test)
             if (t == 0) D.ene[py * nx + px] = ener0;
             const int wq = (py - ij) * pw + (px - ii);                            // the neighbour lies in the window
             if (heap_size < D.heap_cap) heap_push_wave(heap, heap_size, px, py, sm.a[wq], sm.b[wq], new_ener);
@@ -85,7 +82,7 @@ __device__ __forceinline__ void twin_push(const GrowDir &D, GrowShared &sm, size
         }
     }
     const int g = j * nx + i, wq = (j - ij) * pw + (i - ii);                      // :718-726
-    if (t == 0 && n.cene > ener0) {
+    if (t == 0 && lane_read(n.nene, 4) > ener0) {
         D.out[g] = sm.a[wq];
         D.out[pe + g] = sm.b[wq];
         D.ene[g] = ener0;
@@ -272,7 +269,7 @@ __global__ __launch_bounds__(K * kPatchThreads) void grow_kernel_twin(const Grow
             for (int s = 0; s < K; ++s)
                 if (s <= ng) {
                     twin_neigh_load(D, nx, ny, S.ctl[8 + 4 * s], S.ctl[9 + 4 * s], nb[s]);
-                    if (s > 0) nb[s].cene = S.cand[s][0];                         // the centre's energy once its fix is in (:932)
+                    if (s > 0 && lane == 4) nb[s].nene = S.cand[s][0];            // the centre's energy once its fix is in (:932)
                 }
         }
         float u1 = 0.0f, u2 = 0.0f;
