@@ -58,12 +58,13 @@ namespace {
 // Host containers may throw; nothing crosses the C ABI.
 // Development hooks.  Everything the library reads from the environment that is NOT product behaviour -- tuning aids (FALDOI_TILE,
 // FALDOI_PERSIST_CFG, FALDOI_NL_ROWS, FALDOI_HEAP_TOP_LEVELS, FALDOI_WARP_LDS, FALDOI_WARP_WPS, FALDOI_SYNC_GROUP), measurement aids
-// (FALDOI_STAMPS, FALDOI_EVENT_TIMING, FALDOI_CHUNK_REPEAT, FALDOI_WARP_REPEAT: bench.py times kernels with the last two), and test
+// (FALDOI_STAMPS, FALDOI_GROW_DETAIL, FALDOI_REPLAY_CYCLES, FALDOI_EVENT_TIMING, FALDOI_CHUNK_REPEAT, FALDOI_WARP_REPEAT: bench.py times
+// kernels with the last two), and test
 // hooks that force a rare path (FALDOI_PERSIST_SPINS, FALDOI_GROW_DENSE, FALDOI_RESEED, FALDOI_TVCSAD_SERIAL_SUM, FALDOI_CSAD_SORT,
 // FALDOI_NL_CHECK_SELFTEST, FALDOI_SELFTEST_DUMP) -- goes through dev_env(), and ONE compile-time switch removes them all:
 // -DFALDOI_DEV_HOOKS=0 builds a library that reads only the three documented switches (FALDOI_PERSIST, FALDOI_EXACT_QUOTIENTS,
 // FALDOI_NL_FUSED).  The default build keeps the hooks: the suites and bench.py use them.  (The timing-only what-if
-// variants of the kernels are compile-time already: FALDOI_WHATIF, FALDOI_NFWHATIF, never defined in a product build.)
+// variants of the kernels are compile-time already: FALDOI_WHATIF, FALDOI_NFWHATIF, FALDOI_HEAP_STAMPS, never defined in a product build.)
 #ifndef FALDOI_DEV_HOOKS
 #define FALDOI_DEV_HOOKS 1
 #endif
