@@ -283,9 +283,10 @@ def test_growing_with_several_windows_at_a_time_is_the_sequential_growing(ctx, o
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("top_levels", [0, 2, 5, 9, 13])
-def test_device_queue_wide_rounds_and_in_register_placement(ctx, monkeypatch, top_levels):
-    # a pop below the LDS levels walks eight levels per trip (registers of depth 6, 7, 8) and places the last element from the path in
-    # registers; every split between LDS and global levels, ties, long runs of pops down to the empty queue, against the host queue
+def test_device_queue_rounds_of_six_levels_and_in_register_placement(ctx, monkeypatch, top_levels):
+    # a pop walks six levels per trip (one vector comparison decides all 63 nodes, the path is marked lane-parallel; a second register
+    # holds depth 6) and places the last element from the path in registers; every split between LDS and global levels, ties, long
+    # runs of pops down to the empty queue, against the host queue (itself tested against std::priority_queue)
     monkeypatch.setenv("FALDOI_HEAP_TOP_LEVELS", str(top_levels))
     rng = np.random.default_rng(40 + top_levels)
     for levels, n, ppush in ((3, 300, 0.6), (100000, 65000, 0.75), (7, 65000, 0.66), (1000, 40000, 0.52), (100000, 3000, 0.5)):
