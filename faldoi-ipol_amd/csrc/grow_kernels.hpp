@@ -88,6 +88,7 @@ struct GrowShared {
     int err[4];                       // max |du|^2 (float bits) per wavefront, double-buffered
     int res[2];                       // harmonic fill: offset of each channel's level-0 result from ver[c][0]
     int cur[4];                       // {have, i, j, pixel}
+    int vote[2];                      // trust test: per wavefront, its part of the window has a pixel that is not trusted
 };
 
 }  // namespace faldoi
@@ -110,6 +111,20 @@ namespace faldoi {
 __device__ __forceinline__ float lane_read(float v, int lane)    // lane: wave-uniform
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// max of a wavefront's values, all >= 0 (a shifted-in 0 is neutral; `a > b ? a : b` on NaN-free operands is order-independent): four
+// row shifts leave each 16-lane row's maximum in its last lane, two row broadcasts carry them to lane 63
+__device__ __forceinline__ float wave_max_nonneg(float v)
+{
+    float o;
+    o = __builtin_amdgcn_update_dpp(0.0f, v, 0x111, 0xf, 0xf, true); v = o > v ? o : v;      // row_shr:1
+    o = __builtin_amdgcn_update_dpp(0.0f, v, 0x112, 0xf, 0xf, true); v = o > v ? o : v;      // row_shr:2
+    o = __builtin_amdgcn_update_dpp(0.0f, v, 0x114, 0xf, 0xf, true); v = o > v ? o : v;      // row_shr:4
+    o = __builtin_amdgcn_update_dpp(0.0f, v, 0x118, 0xf, 0xf, true); v = o > v ? o : v;      // row_shr:8
+    o = __builtin_amdgcn_update_dpp(0.0f, v, 0x142, 0xa, 0xf, false); v = o > v ? o : v;     // row_bcast:15 into rows 1 and 3
+    o = __builtin_amdgcn_update_dpp(0.0f, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;     // row_bcast:31 into rows 2 and 3
+    return lane_read(v, 63);
 }
 
 __device__ __forceinline__ void wave_sync()
@@ -508,13 +523,10 @@ __device__ __forceinline__ float window_solve(GrowShared &sm, float *base, size_
             const float uN = primal_step(u1, u2, ub1, ub2, v1, v2, d1, d2, theta, rtheta, tau);   // :122-166, :420-427
             uNr = uN > 0.0f ? uN : 0.0f;                                          // NaN never wins, as in the reference
         }
-        // max over the window: butterfly inside each wavefront, then one LDS word per wavefront
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float other = __shfl_xor(uNr, o, 64);
-            uNr = other > uNr ? other : uNr;
-        }
-        if ((t & 63) == 0 && go) sm.err[2 * (it & 1) + (t >> 6)] = __float_as_int(uNr);
+        // max over the window: inside each wavefront by six DPP steps (a `__shfl_xor` butterfly is six dependent trips through the
+        // LDS crossbar per iteration), then one LDS word per wavefront
+        const float wmax = wave_max_nonneg(uNr);
+        if ((t & 63) == 0 && go) sm.err[2 * (it & 1) + (t >> 6)] = __float_as_int(wmax);
         sm.a[t] = ub1;
         sm.b[t] = ub2;
         __syncthreads();
@@ -912,7 +924,13 @@ __device__ __forceinline__ void add_neighbors_dev(GrowShared &sm, NlShared *ns, 
     const bool act = t < pw * ph;
     const int p = (ij + (act ? t / pw : 0)) * nx + ii + (act ? t % pw : 0);
     bool fill = iteration == 0;
-    if (!fill) fill = __syncthreads_or(act && D.trust[p] == 0);                   // check_trustable_patch :639-656
+    if (!fill) {                                                                  // check_trustable_patch :639-656: each wavefront votes on
+        // its part of the window, one barrier (a __syncthreads_or is two and an LDS atomic)
+        const unsigned long long vote = __builtin_amdgcn_ballot_w64(act && D.trust[p] == 0);
+        if ((t & 63) == 0) sm.vote[t >> 6] = vote != 0ull ? 1 : 0;
+        __syncthreads();
+        fill = (sm.vote[0] | sm.vote[1]) != 0;
+    }
     // first wavefront (uniformly): state of the four neighbours and of the centre, read now so that the latency
     // hides behind the window computation (only lane 0 ever writes these arrays during a growing)
     // (lane q < 4 holds neighbour q's state, lane 4 the centre's: one set of loads for all five)
