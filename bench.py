@@ -181,8 +181,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--growing-pairs", type=int, default=512)
-    ap.add_argument("--whole-image-full", action="store_true",
-                    help="the whole-image growing leg on the full 1024x436 frames instead of a 512x256 crop (about a minute more)")
+    ap.add_argument("--whole-image-crop", action="store_true",
+                    help="the whole-image growing leg on a 512x256 crop instead of the full 1024x436 frames (about 50 s less; what "
+                         "tools/profile_bench.sh passes)")
+    ap.add_argument("--whole-image-full", action="store_true", help="(the default now; accepted for older command lines)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU test hook for the N-rank launcher: gloo backend, a stub step, no GPU; the line it "
                          "prints is labelled as such and is not a measurement")
@@ -868,7 +870,8 @@ def local_step_leg(out, args, F, np, ctx, full0, full1):
     fh2, fh3 = os.path.join(ROOT, "tests", "golden", "sintel_final_hard_frame_0002.png"), os.path.join(ROOT, "tests", "golden", "sintel_final_hard_frame_0003.png")
     if os.path.exists(fh2) and os.path.exists(fh3):
         from util import load_rgb_planar
-        crop = None if args.whole_image_full else (256, 100, 512, 256)          # --whole-image-full: the 1024x436 frames (about a minute more)
+        full = not args.whole_image_crop                                         # the 1024x436 frames unless --whole-image-crop
+        crop = None if full else (256, 100, 512, 256)
         c0, c1 = load_rgb_planar(fh2, crop), load_rgb_planar(fh3, crop)
         if crop is None:
             crop = (0, 0, c0.shape[2], c0.shape[1])
@@ -877,7 +880,7 @@ def local_step_leg(out, args, F, np, ctx, full0, full1):
         t0 = time.perf_counter()
         wflow, _, wst = ctx.match_growing(ca, cb, csd[0], csd[1], preprocessed=1)
         t_dev = time.perf_counter() - t0
-        leg = {"size": ("%dx%d crop of final/hard" if not args.whole_image_full else "%dx%d, final/hard") % (crop[2], crop[3]), "mode": "-split_img 0 (whole image: forward and backward growing, two workgroups)",
+        leg = {"size": ("%dx%d crop of final/hard" if not full else "%dx%d, final/hard") % (crop[2], crop[3]), "mode": "-split_img 0 (whole image: forward and backward growing, two workgroups)",
                "windows": int(sum(wst.solves)), "device_s": round(t_dev, 2), "windows_per_s": round(sum(wst.solves) / t_dev, 0),
                "kernel": "grow_kernel_twin<4> (guessed next pops computed beside the current window, committed in pop order)"}
         if not args.no_cpu_baseline:
@@ -887,9 +890,8 @@ def local_step_leg(out, args, F, np, ctx, full0, full1):
             t_cpu = time.perf_counter() - t0
             leg.update({"cpu_checker_s": round(t_cpu, 2), "cpu_threads": 2, "device_over_cpu_time": round(t_dev / t_cpu, 3),
                         "bit_identical": bool(np.array_equal(wflow.view(np.uint32), oflow.view(np.uint32)))})
-        if not args.whole_image_full:
-            leg["full_size_recorded"] = ("1024x436 (python bench.py --whole-image-full, profiles/r04_bench_whole_image_full.json): the device's "
-                                         "advantage grows with the queue -- the checker's no longer fits its caches")
+        if not full:
+            leg["full_size"] = "the default bench line runs this leg on the 1024x436 frames (profiles/r04_bench_line.json)"
         out["secondary"]["local_whole_image_growing_one_pair"] = leg
     # BASELINE configs[2]'s chain on this pair, bounded: the local step above (in the reference's partition mode) followed by
     # the global step with the reference's defaults, from the frames in host memory to the final flow in host memory

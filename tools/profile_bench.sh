@@ -7,7 +7,7 @@
 #   -> gpurun_out/prof_r03/{counters.json, kernel_stats.csv, *.log}
 set -e
 TAG=${1:-r03}
-ARGS=${2:---steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${2:---steps 3 --warmup 1 --no-cpu-baseline --whole-image-crop}
 TILE=${3:-4,16,10,1,1024x436}
 PTILE=${4:-3,16,5,1,1024x436,300,10}
 OUT=gpurun_out/prof_$TAG
