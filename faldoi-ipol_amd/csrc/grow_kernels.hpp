@@ -337,18 +337,25 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
         const int roff = (ic < w - 1) ? 1 : 0, loff = (ic > 0) ? 1 : 0;
         int base = ic;                                                // row clamp(j, 0, h-1) = 0 at the start (j <= 0)
         unsigned hs = lane_on ? holes : 0u, hl = holes_left;
-        float self = yo[base], right = yo[base + roff], down = yo[base + ((h > 1) ? w : 0)], sleft = y0[base - loff];
+        // Two steps per trip, written out: what a step loads for the next one (`n`) is what the step after it works on (`c`), so
+        // the values change hands by their NAMES and not by register moves (seven per step of a loop the compiler would not
+        // unroll: it contains the wavefront barrier).  A step past the last diagonal finds no hole bit left and changes nothing,
+        // so an odd count is rounded up.
+        struct SweepRow { float self, right, down, sleft; };
+        SweepRow ra = { yo[base], yo[base + roff], yo[base + ((h > 1) ? w : 0)], y0[base - loff] }, rb = ra;
         float self_prev = 0.0f, nw = 0.0f, mx = 0.0f;
         bool up_hole = false;
         const int steps = w + h - 1 + 6;
-#pragma unroll 2
-        for (int st = 0; st < steps; ++st) {
+        auto sweep_step = [&](const SweepRow &cr, SweepRow &nr) {
             const float left_nw = __builtin_amdgcn_update_dpp(0.0f, nw, 0x111, 0xf, 0xf, true);
             const int cur = base;                                     // == j * w + i whenever row j is inside the level
             const int jn = j + 1;
             base += (jn >= 1 && jn <= h - 1) ? w : 0;                 // next row, clamped
-            const float self_n = yo[base], right_n = yo[base + roff], down_n = yo[base + ((jn < h - 1) ? w : 0)];
-            const float sleft_n = y0[base - loff];
+            const float self = cr.self, right = cr.right, down = cr.down, sleft = cr.sleft;
+            nr.self = yo[base];
+            nr.right = yo[base + roff];
+            nr.down = yo[base + ((jn < h - 1) ? w : 0)];
+            nr.sleft = y0[base - loff];
             const bool row_on = j >= 0;                               // rows >= h have no hole bit left
             const bool self_hole = row_on && (hs & 1u);
             if (self_hole) {
@@ -366,9 +373,13 @@ __device__ __forceinline__ void harmonic_fill_window(GrowShared &sm, const float
             hs = row_on ? hs >> 1 : hs;
             hl = row_on ? hl >> 1 : hl;
             self_prev = self;
-            self = self_n; right = right_n; down = down_n; sleft = sleft_n;
             j = jn;
             wave_sync();
+        };
+#pragma unroll 1
+        for (int st = 0; st < steps; st += 2) {
+            sweep_step(ra, rb);
+            sweep_step(rb, ra);
         }
         // max over each 16-lane group: four row shifts accumulate it in the group's last lane (updates are >= 0, and
         // a shifted-in 0 at the row start is neutral)
